@@ -562,3 +562,24 @@ API int ref_decode_frame(const uint8_t *rec, int len, int nch, int framesize, in
 }
 
 API int ref_abi_version() { return 1; }
+
+// ---------------------------------------------------------------- math micro-probes
+#include "common/math.h"
+#include "common/alignbuf.h"
+API double ref_dot(const double *x, const double *y, int n) {
+  return slmath::dot(std::span<const double>(x, (size_t)n), std::span<const double>(y, (size_t)n));
+}
+API double ref_s2pow(const double *x, const double *p, int n) {
+  std::vector<double, align_alloc<double>> pa(p, p + n);
+  return slmath::calc_s2pow(std::span<const double>(x, (size_t)n), pa);
+}
+API int ref_ldlt(const double *A, int n, double nu, const double *b, double *w) {
+  vec2D m(n, vec1D(n));
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) m[i][j] = A[i * n + j];
+  slmath::LDLT ldlt(n);
+  vec1D bb(b, b + n), ww(w, w + n);
+  int ok = ldlt.Factor(m, nu);
+  if (ok) ldlt.Solve(bb, ww);
+  for (int i = 0; i < n; i++) w[i] = ww[i];
+  return ok;
+}
