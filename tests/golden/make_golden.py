@@ -1,0 +1,99 @@
+"""Generate tests/golden/ref_golden.npz from the GENUINE reference (oracle/_ref/libsacref.so,
+built by `make -C oracle ref` from /root/reference/src).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The file holds inputs and expected outputs only (no reference source text).
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from golden_cases import FRAMESIZE, frame_cases, trace_cases  # noqa: E402
+from oracle_api import Checker, center_frame  # noqa: E402
+
+
+def main():
+    R = Checker("ref")
+    out = {}
+    P = R.profile()
+    out["profile"] = P
+    fwd, inv = R.domain_tables()
+    out["domain_crc"] = np.array([zlib.crc32(fwd.tobytes()), zlib.crc32(inv.tobytes())], np.uint64)
+    out["domain_fwd_sample"] = fwd[::257].copy()
+    out["domain_inv_sample"] = inv[::31].copy()
+
+    # whole-frame records (+ search traces)
+    for name, (raw, cfg) in frame_cases().items():
+        r = R.encode_frame(raw, cfg, FRAMESIZE, trace=True)
+        out[f"frame/{name}/raw"] = raw
+        out[f"frame/{name}/record"] = np.frombuffer(r["record"], np.uint8)
+        out[f"frame/{name}/profile"] = r["profile"]
+        out[f"frame/{name}/info"] = r["info"]
+        if cfg.optimize:
+            out[f"frame/{name}/trace_cost"] = r["trace_cost"]
+            out[f"frame/{name}/trace_coefs"] = r["trace_coefs"]
+
+    # predictor traces (fp64 bit patterns)
+    for name, (raw, coefs, opt, start, n) in trace_cases(P).items():
+        smp, stats = center_frame(raw)
+        pd, plpc, plms, err = R.predict_trace(smp, stats, coefs, start, n, opt)
+        out[f"trace/{name}/raw"] = raw
+        out[f"trace/{name}/coefs"] = coefs
+        out[f"trace/{name}/pd"] = pd
+        out[f"trace/{name}/plpc"] = plpc
+        out[f"trace/{name}/plms"] = plms
+        out[f"trace/{name}/err"] = err
+
+    # coder trace: first 20000 (p1,bit) decisions + bytes for one residual vector
+    rng = np.random.default_rng(11)
+    e = np.rint(rng.laplace(size=4000) * 150).astype(np.int32)
+    u = np.where(e < 0, -2 * e, np.where(e > 0, 2 * e - 1, 0)).astype(np.int32)
+    mb = int(u.max()).bit_length() - 1
+    cnt, p1, bits = R.bitplane_trace(u, mb, 20000)
+    out["coder/s2u"] = u
+    out["coder/maxbpn"] = np.array([mb, cnt], np.int64)
+    out["coder/p1"] = p1
+    out["coder/bits"] = bits
+    out["coder/bytes"] = np.frombuffer(R.bitplane_encode(u, mb), np.uint8)
+
+    # costs
+    e2 = np.rint(rng.laplace(size=3000) * 40).astype(np.int32)
+    out["cost/err"] = e2
+    out["cost/values"] = np.array([R.cost(k, e2) for k in range(5)])
+
+    # RNG / search helpers (pins libstdc++ <random> behaviour on whatever host runs the tests)
+    kinds = rng.integers(0, 3, 1000).astype(np.int32)
+    out["rng/kinds"] = kinds
+    out["rng/values"] = R.rng(kinds, np.full(1000, 55.0))
+    out["rng/gen_norm"] = R.gen_norm(0.3, 0.0, 1.0, 0.2, 300)
+    nd = 12
+    lo = np.zeros(nd); hi = np.arange(1, nd + 1) * 1.0
+    for nt in (0, 4):
+        best, xb, tc = R.dds_quadratic(lo, hi, hi * 0.5, hi * 0.25, 120, nt, 0.2)
+        out[f"dds/q{nt}/xbest"] = xb
+        out[f"dds/q{nt}/trace"] = tc
+
+    # remap
+    raw = frame_cases()["sparse16_normal"][0][0]
+    smp, stats = center_frame(raw[None, :])
+    err, pred = R.predict_frame(smp, stats, P[:, 2].copy(), 0, raw.size, 0)
+    r, s2u_map, mbm, ul, uh = R.remap(raw, pred[0], err[0])
+    out["remap/ratio"] = np.array([r])
+    out["remap/s2u_map"] = s2u_map
+    out["remap/maxbpn"] = np.array([mbm])
+    out["remap/mapbytes"] = np.frombuffer(R.mapencode(ul, uh), np.uint8)
+
+    path = os.path.join(HERE, "ref_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""Shared definition of the parity cases (inputs are regenerated from seeds; the golden file
+also stores the raw PCM so the fixtures do not depend on numpy's RNG staying stable)."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle_api import COST_BITPLANE, frame_cfg
+from sac_amd.synth import synth_pcm
+
+RATE = 8000
+FRAMESIZE = 20 * RATE  # max_framelen(20 s) * rate, libsac.cpp:784
+
+
+def frame_cases():
+    """name -> (raw PCM [nch,n] int32, FrameCfg)."""
+    c = {}
+    c["s16_normal"] = (synth_pcm(6000, 2, 1, RATE), frame_cfg("normal"))
+    c["m16_normal"] = (synth_pcm(6000, 1, 2, RATE), frame_cfg("normal"))
+    c["m8_normal"] = (synth_pcm(6000, 1, 3, RATE, bits=8), frame_cfg("normal"))
+    c["sparse16_normal"] = (synth_pcm(6000, 1, 4, RATE, sparse_bits=10), frame_cfg("normal"))
+    c["sparse16s_normal"] = (synth_pcm(6000, 2, 5, RATE, sparse_bits=9), frame_cfg("normal"))
+    c["s16_high_single"] = (synth_pcm(8000, 2, 6, RATE), frame_cfg("high", maxnfunc=24))
+    c["s16_high_mt4"] = (synth_pcm(8000, 2, 7, RATE), frame_cfg("high", num_threads=4, maxnfunc=24))
+    c["m16_bpncost_mt4"] = (synth_pcm(4000, 1, 8, RATE),
+                            frame_cfg("high", num_threads=4, maxnfunc=10, cost=COST_BITPLANE, fraction=0.02))
+    c["s16_raw_nosparse"] = (synth_pcm(5000, 2, 9, RATE) + 300, frame_cfg("normal", sparse_pcm=0, zero_mean=0))
+    c["tiny_stereo"] = (synth_pcm(40, 2, 10, RATE), frame_cfg("normal"))
+    c["silence_mono"] = (np.zeros((1, 500), np.int32), frame_cfg("normal"))
+    return c
+
+
+def rand_profile(P, rng, cap=True, scale=1.0):
+    """Random point of the search box around the default profile (P = [58,3] vmin,vmax,vdef)."""
+    g = P[:, 2].astype(np.float64).copy()
+    for i in range(58):
+        lo, hi = float(P[i, 0]), float(P[i, 1])
+        if rng.random() < 0.7:
+            g[i] = np.clip(g[i] + rng.standard_normal() * 0.2 * scale * (hi - lo), lo, hi)
+    if cap:  # keep the CPU checkers fast
+        for i, c in zip([28, 29, 30, 37, 31, 32, 33, 38], [600, 200, 64, 16, 600, 200, 64, 16]):
+            g[i] = min(g[i], c)
+    return g.astype(np.float32)
+
+
+def trace_cases(P):
+    """name -> (raw [nch,n], coefs[58], optimize flag, start, n_window)."""
+    rng = np.random.default_rng(5)
+    c = {}
+    c["tr_s16_default_k1"] = (synth_pcm(1500, 2, 20, RATE), P[:, 2].copy(), 0, 0, 1500)
+    c["tr_s16_default_k4_window"] = (synth_pcm(2500, 2, 21, RATE), P[:, 2].copy(), 1, 700, 1200)
+    c["tr_m16_rand_k1"] = (synth_pcm(1500, 1, 22, RATE), rand_profile(P, rng), 0, 0, 1500)
+    g = rand_profile(P, rng); g[27] = -11.0; g[9] = 7.0  # ch_ref swap + nM0>0
+    c["tr_s16_swap_k4"] = (synth_pcm(1500, 2, 23, RATE), g, 1, 0, 1500)
+    g = rand_profile(P, rng); g[27] = 0.0; g[26] = 0.0
+    c["tr_s16_nS1_0"] = (synth_pcm(1200, 2, 24, RATE), g, 0, 0, 1200)
+    g = rand_profile(P, rng); g[24] = 32; g[9] = 32; g[25] = 32; g[26] = 32; g[27] = 32; g[41] = 10
+    c["tr_s16_maxols"] = (synth_pcm(900, 2, 25, RATE), g, 1, 0, 900)
+    c["tr_m8_default"] = (synth_pcm(1500, 1, 26, RATE, bits=8), P[:, 2].copy(), 0, 0, 1500)
+    return c
