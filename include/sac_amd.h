@@ -1,0 +1,134 @@
+/* include/sac_amd.h -- C ABI of libsac_amd.so: the MI355X (gfx950) implementation of Sac's
+ * per-frame encode hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference (slmdev/sac v0.7.25, /root/reference) has no FFI: its seam is the C++ class
+ * surface of libsac.  Each entry point below names the reference interface it stands in for.
+ * A FrameCoder-shaped C++ wrapper over this ABI is in sac_amd/csrc/framecoder.h and the binding
+ * a maintainer would add to the reference is shown in INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success or a negative sacamd_status; nothing throws
+ * across the ABI; the caller owns all host buffers; the context owns all device buffers and one
+ * HIP stream; a context is single-submitter (concurrency is expressed by batching frames and
+ * candidates), distinct contexts are independent.  There is no CPU fallback: if no gfx950
+ * device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
+ */
+#ifndef SAC_AMD_H
+#define SAC_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SACAMD_NUM_COEFS 58 /* SacProfile::LoadBaseProfile, libsac/profile.cpp:9 */
+
+typedef enum sacamd_status {
+  SACAMD_OK = 0,
+  SACAMD_ERR_ARG = -1,      /* bad argument / out of declared capacity */
+  SACAMD_ERR_HIP = -2,      /* HIP runtime error (see sacamd_last_error) */
+  SACAMD_ERR_NOGPU = -3,    /* no usable gfx950 device */
+  SACAMD_ERR_STATE = -4,    /* call order violated (e.g. evaluate before analyse) */
+  SACAMD_ERR_NONFINITE = -5 /* a predictor produced a non-finite value (cascade.h:40-41) */
+} sacamd_status;
+
+/* FrameCoder::SearchCost / SearchMethod, libsac/libsac.h:14-15 */
+enum { SACAMD_COST_L1 = 0, SACAMD_COST_RMS = 1, SACAMD_COST_ENTROPY = 2, SACAMD_COST_GOLOMB = 3, SACAMD_COST_BITPLANE = 4 };
+
+/* FrameCoder::tsac_cfg + toptim_cfg (+ OptDDS::DDSCfg), libsac/libsac.h:19-44, opt/dds.h:12-19,
+ * flattened.  Presets: cmdline.cpp:127-156. */
+typedef struct sacamd_cfg {
+  int optimize;      /* tsac_cfg.optimize */
+  int sparse_pcm;    /* tsac_cfg.sparse_pcm (default 1) */
+  int zero_mean;     /* tsac_cfg.zero_mean (default 1) */
+  int reset;         /* toptim_cfg.reset  (--opt-reset) */
+  double fraction;   /* toptim_cfg.fraction */
+  int maxnfunc;      /* toptim_cfg.maxnfunc == DDSCfg.nfunc_max */
+  int num_threads;   /* toptim_cfg.num_threads == DDSCfg.num_threads: 0 = sequential run_single,
+                        N>0 = run_mt with N candidates per generation (--opt-cfg=dds,N) */
+  double sigma;      /* DDSCfg.sigma_init */
+  int optk;          /* toptim_cfg.optk (default 4) */
+  int optimize_cost; /* SACAMD_COST_* */
+} sacamd_cfg;
+
+typedef struct sacamd_ctx sacamd_ctx;
+
+/* ---- context -------------------------------------------------------------------------
+ * Replaces: FrameCoder::FrameCoder(numchannels, framesize, cfg) buffer ownership
+ * (libsac.cpp:13-35), for a BATCH of max_frames frames of <= max_framesize samples/channel. */
+int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames, sacamd_ctx **out);
+void sacamd_ctx_destroy(sacamd_ctx *ctx);
+const char *sacamd_last_error(const sacamd_ctx *ctx);
+int sacamd_default_profile(float *vmin, float *vmax, float *vdef); /* profile.cpp:3-89; each [58] */
+void sacamd_default_cfg(sacamd_cfg *cfg);                          /* libsac.h:19-44 defaults */
+
+/* ---- (1) frame staging ------------------------------------------------------------------
+ * Replaces: the caller filling FrameCoder::samples[ch][0..n) + SetNumSamples
+ * (libsac.cpp:822-825).  `framesize` is the reference's max frame size (max_framelen*rate,
+ * libsac.cpp:784) used for the search-window length.  Host or device pointers. */
+int sacamd_frames_upload_i32(sacamd_ctx *ctx, int nframes, int framesize, const int32_t *pcm_planar,
+                             long long frame_stride, long long ch_stride, const int *numsamples);
+/* interleaved little-endian int16 (L R L R ...), frame f starts at sample-frame frame_offset[f] */
+int sacamd_frames_upload_s16(sacamd_ctx *ctx, int nframes, int framesize, const int16_t *pcm_interleaved,
+                             const long long *frame_offset, const int *numsamples);
+/* same, but pcm_interleaved is a DEVICE pointer already resident in HBM (no copy) */
+int sacamd_frames_attach_s16_device(sacamd_ctx *ctx, int nframes, int framesize, const int16_t *d_pcm_interleaved,
+                                    const long long *frame_offset, const int *numsamples);
+
+/* ---- (2) analyse --------------------------------------------------------------------------
+ * Replaces: the head of FrameCoder::Predict (libsac.cpp:445-459): AnalyseMonoChannel
+ * (mean/min/max, :626-651), Remap::Analyse (map.cpp:126-157), mean removal. */
+int sacamd_analyse(sacamd_ctx *ctx, const sacamd_cfg *cfg);
+int sacamd_get_stats(sacamd_ctx *ctx, int32_t *out /* [nframes][nch][4] = mean,min,max,numsamples */);
+
+/* ---- (3) batched candidate evaluation ----------------------------------------------------
+ * Replaces: the search objective cost_func(x) (libsac.cpp:389-397) == PredictFrame(optimize=
+ * true) over the centred search window + GetCost, and its batch form Opt::eval_points_mt
+ * (opt/opt.cpp:11-43), for ncand (frame, profile) pairs at once.  coefs are the float32-
+ * narrowed profiles.  costs[i] is the sum over channels, in bytes (cost.h). */
+int sacamd_evaluate(sacamd_ctx *ctx, const sacamd_cfg *cfg, int ncand, const int *cand_frame,
+                    const float *coefs /* [ncand][58] */, double *costs /* [ncand] */);
+
+/* ---- (4) final prediction pass -------------------------------------------------------------
+ * Replaces: PredictFrame(base_profile, error, 0, numsamples, false) + CnvError_S2U
+ * (libsac.cpp:477-478, 429-441).  One profile per staged frame. */
+int sacamd_predict_final(sacamd_ctx *ctx, const sacamd_cfg *cfg, const float *coefs /* [nframes][58] */);
+/* FrameCoder public buffers error / pred / s2u_error, framestats[].maxbpn (libsac.h:54-56) */
+int sacamd_get_residuals(sacamd_ctx *ctx, int frame, int32_t *error, int32_t *pred, int32_t *s2u,
+                         int *maxbpn /* each [nch][numsamples]; any may be NULL */);
+
+/* ---- (5) entropy coding -------------------------------------------------------------------
+ * Replaces: FrameCoder::Encode (libsac.cpp:486-494): per channel EncodeMonoFrame (:253-278) =
+ * BitplaneCoder + RangeCoderSH over s2u_error (:201-212), CalcRemapError (:230-251) and, when
+ * the ratio is > 1.05, the MapEncoder + mapped variant (:214-228), keeping the smaller. */
+int sacamd_encode(sacamd_ctx *ctx, const sacamd_cfg *cfg);
+int sacamd_get_encoded(sacamd_ctx *ctx, int frame, int ch, uint8_t *out, int cap, int *len,
+                       int *mapped, int *maxbpn);
+
+/* ---- (6) whole batch: Predict + Encode + WriteEncoded -------------------------------------
+ * Replaces: the per-frame sequence FrameCoder::Predict(); Encode(); WriteEncoded()
+ * (libsac.cpp:827-829, 443-479, 565-578) for every staged frame, including the DDS search
+ * (opt/dds.cpp) run in lock-step generations across frames.
+ * profiles_io [nframes][58]: in = search start point per frame (cfg.reset!=0: ignored, the base
+ * profile is used, == --opt-reset); out = profile written into each record.
+ * out receives the frame records back to back; rec_off[f]..rec_off[f+1] delimit frame f. */
+int sacamd_encode_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles_io, uint8_t *out,
+                         long long cap, long long *rec_off /* [nframes+1] */);
+
+/* ---- parity taps (tests) -------------------------------------------------------------------
+ * Per-stage streams of one frame for one profile: p_lpc, p_lpc+p_lms (file-channel order),
+ * residual and pred, over window [start,start+n).  == oracle predict_trace. */
+int sacamd_debug_predict(sacamd_ctx *ctx, int frame, const float *coefs, int start, int n,
+                         int optimize, int optk, double *plpc, double *psum, int32_t *err, int32_t *pred);
+/* bitplane coder on an arbitrary s2u vector (== BitplaneCoder::Encode + RangeCoderSH) */
+int sacamd_debug_bitplane(sacamd_ctx *ctx, const int32_t *s2u, int n, int maxbpn, uint8_t *out, int cap, int *len);
+/* cost function on an arbitrary residual vector (== CostFunction::Calc, cost.h) */
+int sacamd_debug_cost(sacamd_ctx *ctx, int kind, const int32_t *err, int n, double *cost);
+/* time spent (ms, HIP events on the context's stream) in each kernel family since the last call:
+ * [0] analyse [1] tables [2] ols [3] lms [4] bias [5] cost [6] s2u/remap [7] coder; launches in [8..15] */
+int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
+
+int sacamd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

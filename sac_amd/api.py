@@ -1,0 +1,219 @@
+"""ctypes binding of libsac_amd.so (the C ABI in include/sac_amd.h) plus a thin, FrameCoder-shaped
+Python host layer used by tests and bench.py.  There is no CPU fallback: if the HIP library is
+missing, or no gfx950 device is present, construction fails loudly."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_longlong, c_void_p
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsac_amd.so")
+NUM_COEFS = 58
+COST_L1, COST_RMS, COST_ENTROPY, COST_GOLOMB, COST_BITPLANE = 0, 1, 2, 3, 4
+
+ABI_SYMBOLS = [
+    "sacamd_ctx_create", "sacamd_ctx_destroy", "sacamd_last_error", "sacamd_default_profile",
+    "sacamd_default_cfg", "sacamd_frames_upload_i32", "sacamd_frames_upload_s16",
+    "sacamd_frames_attach_s16_device", "sacamd_analyse", "sacamd_get_stats", "sacamd_evaluate",
+    "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
+    "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
+    "sacamd_kernel_times", "sacamd_abi_version",
+]
+
+
+class SacAmdError(RuntimeError):
+    pass
+
+
+class Cfg(ctypes.Structure):
+    """sacamd_cfg == FrameCoder::tsac_cfg + toptim_cfg flattened (libsac/libsac.h:19-44)."""
+    _fields_ = [("optimize", c_int), ("sparse_pcm", c_int), ("zero_mean", c_int), ("reset", c_int),
+                ("fraction", c_double), ("maxnfunc", c_int), ("num_threads", c_int), ("sigma", c_double),
+                ("optk", c_int), ("optimize_cost", c_int)]
+
+
+_PRESETS = {  # cmdline.cpp:127-156
+    "normal": (0, 0.0, 0, 0.2, COST_ENTROPY),
+    "high": (1, 0.1, 100, 0.20, COST_ENTROPY),
+    "veryhigh": (1, 0.2, 300, 0.25, COST_ENTROPY),
+    "extrahigh": (1, 0.2, 600, 0.25, COST_ENTROPY),
+    "best": (1, 0.5, 1000, 0.25, COST_BITPLANE),
+    "insane": (1, 0.5, 1500, 0.25, COST_BITPLANE),
+}
+
+
+def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, fraction=None,
+             maxnfunc=None, cost=None, optk=4, sigma=None) -> Cfg:
+    o, f, e, s, c = _PRESETS[mode]
+    return Cfg(o, sparse_pcm, zero_mean, reset, f if fraction is None else fraction,
+               e if maxnfunc is None else maxnfunc, num_threads, s if sigma is None else sigma, optk,
+               c if cost is None else cost)
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SacAmdError(f"{LIB_PATH} not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.sacamd_last_error.restype = c_char_p
+        _lib.sacamd_last_error.argtypes = [c_void_p]
+        _lib.sacamd_ctx_destroy.argtypes = [c_void_p]
+    return _lib
+
+
+def _vp(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_void_p)
+
+
+def default_profile() -> np.ndarray:
+    """[58,3] = vmin, vmax, vdef (SacProfile::LoadBaseProfile)."""
+    lib = load_library()
+    out = np.zeros((3, NUM_COEFS), np.float32)
+    lib.sacamd_default_profile(_vp(out[0]), _vp(out[1]), _vp(out[2]))
+    return np.ascontiguousarray(out.T)
+
+
+class Context:
+    """One device context: a batch of up to max_frames frames of nch channels."""
+
+    def __init__(self, nch: int, max_framesize: int, max_frames: int, device: int = 0):
+        self.lib = load_library()
+        self.nch, self.max_framesize, self.max_frames = nch, max_framesize, max_frames
+        h = c_void_p()
+        rc = self.lib.sacamd_ctx_create(device, nch, max_framesize, max_frames, byref(h))
+        if rc != 0:
+            raise SacAmdError(f"sacamd_ctx_create failed ({rc}): no usable gfx950 device / HIP error")
+        self.h = h
+        self.nframes = 0
+        self.numsamples = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sacamd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SacAmdError(f"sacamd error {rc}: {self.lib.sacamd_last_error(self.h).decode()}")
+
+    # ---- staging
+    def upload_i32(self, frames, framesize: int):
+        """frames: list of int32 arrays [nch, n_f] (raw, un-centred PCM)."""
+        nf = len(frames)
+        ns = np.array([f.shape[1] for f in frames], np.int32)
+        stride = int(ns.max())
+        buf = np.zeros((nf, self.nch, stride), np.int32)
+        for i, f in enumerate(frames):
+            buf[i, :, : f.shape[1]] = f
+        self._chk(self.lib.sacamd_frames_upload_i32(self.h, nf, framesize, _vp(buf), c_longlong(self.nch * stride),
+                                                    c_longlong(stride), _vp(ns)))
+        self.nframes, self.numsamples = nf, ns
+
+    def upload_s16(self, interleaved: np.ndarray, frame_offset, numsamples, framesize: int):
+        """interleaved: int16 [total_sample_frames, nch]; frame f = rows frame_offset[f] .. +numsamples[f]."""
+        il = np.ascontiguousarray(interleaved, np.int16)
+        fo = np.ascontiguousarray(frame_offset, np.int64)
+        ns = np.ascontiguousarray(numsamples, np.int32)
+        self._chk(self.lib.sacamd_frames_upload_s16(self.h, len(ns), framesize, _vp(il), _vp(fo), _vp(ns)))
+        self.nframes, self.numsamples = len(ns), ns
+
+    def attach_s16_device(self, dev_ptr: int, frame_offset, numsamples, framesize: int):
+        fo = np.ascontiguousarray(frame_offset, np.int64)
+        ns = np.ascontiguousarray(numsamples, np.int32)
+        self._chk(self.lib.sacamd_frames_attach_s16_device(self.h, len(ns), framesize, c_void_p(dev_ptr), _vp(fo), _vp(ns)))
+        self.nframes, self.numsamples = len(ns), ns
+
+    # ---- path stages
+    def analyse(self, cfg: Cfg):
+        self._chk(self.lib.sacamd_analyse(self.h, byref(cfg)))
+
+    def stats(self) -> np.ndarray:
+        out = np.zeros((self.nframes, self.nch, 4), np.int32)
+        self._chk(self.lib.sacamd_get_stats(self.h, _vp(out)))
+        return out
+
+    def evaluate(self, cfg: Cfg, cand_frame, coefs) -> np.ndarray:
+        cf = np.ascontiguousarray(cand_frame, np.int32)
+        g = np.ascontiguousarray(coefs, np.float32).reshape(len(cf), NUM_COEFS)
+        costs = np.zeros(len(cf))
+        self._chk(self.lib.sacamd_evaluate(self.h, byref(cfg), len(cf), _vp(cf), _vp(g), _vp(costs)))
+        return costs
+
+    def predict_final(self, cfg: Cfg, coefs):
+        g = np.ascontiguousarray(coefs, np.float32).reshape(self.nframes, NUM_COEFS)
+        self._chk(self.lib.sacamd_predict_final(self.h, byref(cfg), _vp(g)))
+
+    def residuals(self, frame: int):
+        n = int(self.numsamples[frame])
+        err = np.zeros((self.nch, n), np.int32); pred = np.zeros((self.nch, n), np.int32)
+        s2u = np.zeros((self.nch, n), np.int32); mb = np.zeros(self.nch, np.int32)
+        self._chk(self.lib.sacamd_get_residuals(self.h, frame, _vp(err), _vp(pred), _vp(s2u), _vp(mb)))
+        return err, pred, s2u, mb
+
+    def encode(self, cfg: Cfg):
+        self._chk(self.lib.sacamd_encode(self.h, byref(cfg)))
+
+    def encoded(self, frame: int, ch: int):
+        n = int(self.numsamples[frame])
+        out = np.zeros(n * 4 + 40000, np.uint8)
+        ln, mp, mb = c_int(0), c_int(0), c_int(0)
+        self._chk(self.lib.sacamd_get_encoded(self.h, frame, ch, _vp(out), out.size, byref(ln), byref(mp), byref(mb)))
+        return out[: ln.value].tobytes(), mp.value, mb.value
+
+    def encode_frames(self, cfg: Cfg, profiles=None):
+        """Predict + Encode + WriteEncoded for every staged frame -> (list of records, profiles)."""
+        prof = np.zeros((self.nframes, NUM_COEFS), np.float32)
+        if profiles is None:
+            prof[:] = default_profile()[:, 2]
+        else:
+            prof[:] = np.asarray(profiles, np.float32).reshape(self.nframes, NUM_COEFS)
+        cap = int(self.numsamples.astype(np.int64).sum()) * self.nch * 4 + self.nframes * (4096 * 2 + 70000)
+        out = np.zeros(cap, np.uint8)
+        off = np.zeros(self.nframes + 1, np.int64)
+        self._chk(self.lib.sacamd_encode_frames(self.h, byref(cfg), _vp(prof), _vp(out), c_longlong(cap), _vp(off)))
+        recs = [out[off[f]: off[f + 1]].tobytes() for f in range(self.nframes)]
+        return recs, prof
+
+    # ---- parity taps
+    def debug_predict(self, frame, coefs, start, n, optimize, optk=4):
+        g = np.ascontiguousarray(coefs, np.float32)
+        plpc = np.zeros((self.nch, n)); psum = np.zeros((self.nch, n))
+        err = np.zeros((self.nch, n), np.int32); pred = np.zeros((self.nch, n), np.int32)
+        self._chk(self.lib.sacamd_debug_predict(self.h, frame, _vp(g), start, n, int(optimize), optk, _vp(plpc), _vp(psum),
+                                                _vp(err), _vp(pred)))
+        return plpc, psum, err, pred
+
+    def debug_bitplane(self, s2u, maxbpn) -> bytes:
+        u = np.ascontiguousarray(s2u, np.int32)
+        out = np.zeros(u.size * 4 + 4096, np.uint8)
+        ln = c_int(0)
+        self._chk(self.lib.sacamd_debug_bitplane(self.h, _vp(u), u.size, maxbpn, _vp(out), out.size, byref(ln)))
+        return out[: ln.value].tobytes()
+
+    def debug_cost(self, kind, err) -> float:
+        e = np.ascontiguousarray(err, np.int32)
+        c = c_double(0)
+        self._chk(self.lib.sacamd_debug_cost(self.h, kind, _vp(e), e.size, byref(c)))
+        return c.value
+
+    def kernel_times(self, reset=True):
+        out = np.zeros(16)
+        self._chk(self.lib.sacamd_kernel_times(self.h, _vp(out), int(reset)))
+        names = ["analyse", "tables", "ols", "lms", "bias", "cost", "s2u_remap", "coder"]
+        return {n: {"ms": out[i], "launches": int(out[8 + i])} for i, n in enumerate(names)}

@@ -1,0 +1,71 @@
+// sac_amd/csrc/canon.h -- the "canonical arithmetic" of the reference binary, as host/device
+// inline functions with every fused multiply-add explicit (compile with -ffp-contract=off).
+//
+// These follow slmath::dot / std::transform_reduce / the vectorised fold-left reduction loops as
+// g++ 11 -O3 -mavx2 -mfma compiles /root/reference/src/common/math.h:14-191; DESIGN.md
+// ("canonical arithmetic") explains how the forms were established.  They are used wherever the
+// product must agree with the reference decoder to the last bit (OLS stage, small dots of the
+// RLS / mixer / bias chain).
+#pragma once
+#include "simt.h"
+
+namespace sacamd {
+
+// in-order reduction acc += a[k]*b[k]: groups of 4 and one pair unfused, odd last element fused
+template <class PA, class PB>
+SA_HD double fold_add(double acc, int m, PA a, PB b) {
+  int k = 0;
+  for (; k + 4 <= m; k += 4) {
+    acc = acc + a(k) * b(k);
+    acc = acc + a(k + 1) * b(k + 1);
+    acc = acc + a(k + 2) * b(k + 2);
+    acc = acc + a(k + 3) * b(k + 3);
+  }
+  if (m - k >= 2) {
+    acc = acc + a(k) * b(k);
+    acc = acc + a(k + 1) * b(k + 1);
+    k += 2;
+  }
+  if (k < m) acc = fma(a(k), b(k), acc);
+  return acc;
+}
+
+// true when term k of an m-term fold-left chain is the fused one
+SA_HD bool fold_fused(int k, int m) { return (m & 1) && (k == m - 1); }
+
+// std::transform_reduce(x, x+n, y, 0.0) as compiled
+SA_HD double tr_dot(const double *a, const double *b, int n) {
+  double init = 0.0;
+  while (n >= 4) {
+    const double v1 = fma(a[1], b[1], a[0] * b[0]);
+    const double v2 = fma(a[3], b[3], a[2] * b[2]);
+    init = init + (v1 + v2);
+    a += 4; b += 4; n -= 4;
+  }
+  return fold_add(init, n, [&](int k) { return a[k]; }, [&](int k) { return b[k]; });
+}
+
+// slmath::dot (common/math.h:130-161)
+SA_HD double dot_canon(const double *x, const double *y, int n) {
+  double total = 0.0;
+  int i = 0;
+  if (n >= 8) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (; i + 8 <= n; i += 8) {
+      s0 = fma(x[i], y[i], s0); s1 = fma(x[i + 1], y[i + 1], s1);
+      s2 = fma(x[i + 2], y[i + 2], s2); s3 = fma(x[i + 3], y[i + 3], s3);
+      t0 = fma(x[i + 4], y[i + 4], t0); t1 = fma(x[i + 5], y[i + 5], t1);
+      t2 = fma(x[i + 6], y[i + 6], t2); t3 = fma(x[i + 7], y[i + 7], t3);
+    }
+    s0 = s0 + t0; s1 = s1 + t1; s2 = s2 + t2; s3 = s3 + t3;
+    total = ((s0 + s1) + s2) + s3;
+  }
+  total += tr_dot(x + i, y + i, n - i);
+  return total;
+}
+
+SA_HD double sgnd(double x) { return (double)((x > 0) - (x < 0)); }
+SA_HD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+SA_HD int clampi32(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+}  // namespace sacamd

@@ -1,0 +1,569 @@
+// sac_amd/csrc/host.hip -- host side of libsac_amd.so: context, C ABI (include/sac_amd.h),
+// work-item construction, the DDS search driver and frame-record assembly.
+//
+// Reference call-sites mirrored here (all /root/reference/src):
+//   FrameCoder::Predict / Optimize / cost_func     libsac/libsac.cpp:365-479
+//   OptDDS::generate_candidate / run_single / run_mt  opt/dds.cpp:12-119, Opt helpers opt/opt.cpp
+//   SSC0 / SSC1                                      opt/ssc.h
+//   FrameCoder::Encode / WriteEncoded               libsac/libsac.cpp:486-494, 530-578
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/sac_amd.h"
+#include "coder.h"
+#include "kernels.h"
+#include "params.h"
+
+using namespace sacamd;
+
+#define API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+// ---------------------------------------------------------------- default profile (profile.cpp:3-89)
+struct Coef { float vmin, vmax, vdef; };
+static void load_base_profile(Coef *c) {
+  const int mo = 32, wb = 13;
+  auto S = [&](int i, double a, double b, double d) { c[i] = {(float)a, (float)b, (float)d}; };
+  for (int i = 0; i < kNumCoefs; i++) c[i] = {0.f, 0.f, 0.f};
+  S(0, 0.99, 0.9999, 0.998); S(1, 1.0, 100.0, 25.0);
+  S(2, 0.001, 1.0, 0.1); S(3, 0.001, 1.0, 0.12); S(4, 0.001, 1.0, 0.06); S(5, 0.001, 1.0, 0.04);
+  S(6, 0.98, 1, 1.0); S(7, 0.0, 1.0, 0.8); S(8, 0.0, 1.0, 0.8);
+  S(10, 0.0005, 0.05, 0.005); S(11, 0.8, 0.9999, 0.95);
+  S(12, 0.99, 0.9999, 0.998); S(13, 1.0, 100.0, 25.0);
+  S(14, 0.001, 1.0, 0.1); S(15, 0.001, 1.0, 0.12); S(16, 0.001, 1.0, 0.06); S(17, 0.001, 1.0, 0.04);
+  S(18, 0.98, 1, 1.0); S(19, 0.0, 1.0, 0.8); S(20, 0.0, 1.0, 0.8); S(21, 0.0, 1.0, 0.8);
+  S(22, 0.0005, 0.05, 0.005); S(23, 0.8, 0.9999, 0.95);
+  S(24, 4, mo, 16); S(25, 4, mo, 16); S(26, 0, mo, 8); S(27, -mo, mo, 8); S(9, 0, mo, 0);
+  S(28, 256, 1 << wb, 1280); S(29, 32, 1 << (wb - 1), 256); S(30, 4, 1 << (wb - 2), 32);
+  S(31, 256, 1 << wb, 1280); S(32, 32, 1 << (wb - 1), 256); S(33, 4, 1 << (wb - 2), 32);
+  S(34, 0, 1, 0.5); S(35, 0.1, 2, 0.8); S(36, 0.1, 10, 2);
+  S(53, 0, 1, 0.5); S(54, 0.1, 2, 0.8); S(55, 0.1, 10, 2);
+  S(56, 0.0, 0.5, 0.1); S(57, 0.0, 0.5, 0.1);
+  S(37, 2, 1 << (wb - 3), 4); S(38, 2, 1 << (wb - 3), 4);
+  S(39, 0.98, 1, 1.0); S(40, 0.98, 1, 1.0);
+  S(41, 1, 10, 4); S(42, 0.1, 10.0, 5);
+  S(43, 0.001, 0.005, 0.0015); S(44, 0.001, 0.005, 0.0015);
+  S(45, 4, 10, 5);
+  S(46, 0.98, 1, 1.0); S(48, 0.98, 1, 1.0); S(50, 0.0, 1.0, 0.8);
+  S(47, 0.98, 1, 1.0); S(49, 0.98, 1, 1.0); S(51, 0.0, 1.0, 0.8); S(52, 0.0, 1.0, 0.8);
+}
+
+// ---------------------------------------------------------------- growable device buffer
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+enum { FAM_ANALYSE = 0, FAM_TABLES, FAM_OLS, FAM_LMS, FAM_BIAS, FAM_COST, FAM_S2U, FAM_CODER, FAM_COUNT };
+
+struct TimedSpan { int fam; hipEvent_t a, b; };
+
+}  // namespace
+
+struct sacamd_ctx {
+  int device = 0, nch = 0, max_framesize = 0, max_frames = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // staged batch
+  int nframes = 0, framesize = 0;
+  bool analysed = false, final_done = false, encoded = false;
+  std::vector<int> nsamp;
+  long long ch_stride = 0, frame_stride = 0;
+  DevBuf<int> d_pcm, d_nsamp, d_raw32;
+  DevBuf<int16_t> d_raw16;
+  const int16_t *attached16 = nullptr;
+  DevBuf<long long> d_frame_off;
+  int raw_kind = 0;   // 1: i32 planar in d_raw32, 2: s16 interleaved (own or attached)
+  long long raw_fs = 0, raw_cs = 0;
+  DevBuf<FrameStatsD> d_stats;
+  std::vector<FrameStatsD> h_stats;
+  DevBuf<unsigned char> d_used;
+  // predictor scratch
+  DevBuf<WorkItem> d_items;
+  DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist;
+  DevBuf<double> d_tab, d_p, d_cost;
+  DevBuf<long long> d_off;
+  // final pass products (per frame, channel): offsets (f*nch+ch)*ch_stride
+  DevBuf<int> d_ferr, d_fpred, d_fs2u, d_fs2u_map, d_maxbpn;
+  std::vector<int> h_maxbpn;
+  std::vector<float> final_coefs;
+  // coder
+  DevBuf<unsigned short> d_laplace, d_inv;
+  DevBuf<short> d_fwd;
+  DevBuf<unsigned char> d_cstate, d_cout;
+  DevBuf<int> d_clen;
+  DevBuf<CoderJob> d_jobs;
+  bool coder_tables = false;
+  struct EncOut { std::vector<unsigned char> bytes; int mapped = 0, maxbpn = 0; };
+  std::vector<EncOut> enc;   // [frame*nch+ch]
+  // timing
+  std::vector<TimedSpan> spans;
+  double fam_ms[FAM_COUNT] = {0};
+  long long fam_launches[FAM_COUNT] = {0};
+};
+
+namespace {
+
+int fail(sacamd_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIPCHK(c, expr)                                                                             \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return fail(c, SACAMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+  } while (0)
+
+struct Span {
+  sacamd_ctx *c; TimedSpan t;
+  Span(sacamd_ctx *c_, int fam) : c(c_) {
+    t.fam = fam;
+    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, c->stream);
+  }
+  ~Span() { (void)hipEventRecord(t.b, c->stream); c->spans.push_back(t); c->fam_launches[t.fam]++; }
+};
+
+void collect_spans(sacamd_ctx *c) {
+  for (auto &s : c->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) c->fam_ms[s.fam] += ms;
+    (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+  }
+  c->spans.clear();
+}
+
+int sync_stream(sacamd_ctx *c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  collect_spans(c);
+  return 0;
+}
+
+PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride}; }
+
+// ------------------------------------------------------------ work-item construction
+struct Cand { int frame; const float *coefs; int start, n; bool optimize; int optk; };
+
+int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkItem> &items) {
+  items.clear();
+  long long off_p = 0, off_tab = 0;
+  for (size_t ci = 0; ci < cands.size(); ci++) {
+    const Cand &cd = cands[ci];
+    if (cd.frame < 0 || cd.frame >= c->nframes) return fail(c, SACAMD_ERR_ARG, "candidate frame out of range");
+    ChanParam cp[2]; int ch_ref = 0;
+    map_profile(cd.coefs, cd.optimize, cd.optk, c->nch, &c->h_stats[(size_t)cd.frame * c->nch], cp, &ch_ref);
+    for (int slot = 0; slot < c->nch; slot++) {
+      WorkItem it;
+      std::memset(&it, 0, sizeof(it));
+      it.frame = cd.frame; it.slot = slot;
+      it.ch_self = (c->nch == 2) ? (slot == 0 ? ch_ref : 1 - ch_ref) : 0;
+      it.ch_other = (c->nch == 2) ? 1 - it.ch_self : 0;
+      it.start = cd.start; it.n = cd.n;
+      it.p = cp[slot];
+      const ChanParam &p = it.p;
+      if (p.n_ols < 1 || p.n_ols > 96) return fail(c, SACAMD_ERR_ARG, "OLS order outside [1,96]");
+      if (p.lm_n < 1 || p.lm_n > 10) return fail(c, SACAMD_ERR_ARG, "RLS order outside [1,10]");
+      for (int s = 0; s < 4; s++)
+        if (p.vn[s] < 1 || p.vn[s] > (8192 >> s)) return fail(c, SACAMD_ERR_ARG, "NLMS stage length outside the profile box");
+      it.ols_class = p.n_ols <= 32 ? 0 : (p.n_ols <= 64 ? 1 : 2);
+      const int *vn = p.vn;
+      it.lms_class = (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) ? 0
+                   : (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) ? 1 : 2;
+      it.off_p = off_p; it.off_err = off_p; it.off_tab = off_tab;
+      off_p += cd.n;
+      for (int s = 0; s < 4; s++) off_tab += 2LL * vn[s];
+      items.push_back(it);
+    }
+  }
+  return 0;
+}
+
+// run the three predictor stages for `items`; residual -> d_err (+ d_pred when want_pred)
+int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
+  const int count = (int)items.size();
+  if (!count) return 0;
+  long long tot_p = 0, tot_tab = 0;
+  for (auto &it : items) { tot_p = std::max(tot_p, it.off_p + it.n); tot_tab = std::max(tot_tab, it.off_tab); }
+  const WorkItem &last = items.back();
+  for (int s = 0; s < 4; s++) tot_tab += 2LL * last.p.vn[s];
+  HIPCHK(c, c->d_items.ensure(count));
+  HIPCHK(c, c->d_p.ensure((size_t)tot_p + 512));
+  HIPCHK(c, c->d_err.ensure((size_t)tot_p + 512));
+  if (want_pred) HIPCHK(c, c->d_pred.ensure((size_t)tot_p + 512));
+  HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
+  HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
+  HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
+  // class lists, heaviest first
+  std::vector<int> idx_ols[3], idx_lms[3];
+  for (int i = 0; i < count; i++) { idx_ols[items[i].ols_class].push_back(i); idx_lms[items[i].lms_class].push_back(i); }
+  auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
+  auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
+  std::vector<int> flat;
+  int base_ols[3], base_lms[3];
+  for (int k = 0; k < 3; k++) {
+    std::stable_sort(idx_ols[k].begin(), idx_ols[k].end(), [&](int a, int b) { return olsw(a) > olsw(b); });
+    base_ols[k] = (int)flat.size(); flat.insert(flat.end(), idx_ols[k].begin(), idx_ols[k].end());
+  }
+  for (int k = 0; k < 3; k++) {
+    std::stable_sort(idx_lms[k].begin(), idx_lms[k].end(), [&](int a, int b) { return taps(a) > taps(b); });
+    base_lms[k] = (int)flat.size(); flat.insert(flat.end(), idx_lms[k].begin(), idx_lms[k].end());
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_idx.p, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, c->stream));
+  { Span sp(c, FAM_TABLES); launch_tables(c->stream, c->d_items.p, count, c->d_tab.p); }
+  { Span sp(c, FAM_OLS);
+    for (int k = 0; k < 3; k++) launch_ols(c->stream, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); }
+  { Span sp(c, FAM_LMS);
+    for (int k = 0; k < 3; k++) launch_lms(c->stream, c->d_items.p, c->d_idx.p + base_lms[k], (int)idx_lms[k].size(), k, view(c), c->d_tab.p, c->d_p.p); }
+  { Span sp(c, FAM_BIAS);
+    launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int run_costs(sacamd_ctx *c, int kind, const std::vector<long long> &off, const std::vector<int> &n, const int *d_err,
+              std::vector<double> &out);
+
+void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start, int *nopt) {
+  const int n = c->nsamp[f];
+  const int w = std::min(n, static_cast<int>(std::ceil(c->framesize * cfg->fraction)));   // libsac.cpp:367
+  *nopt = w; *start = (n - w) / 2;
+}
+
+}  // namespace
+
+// ================================================================== context
+API int sacamd_abi_version(void) { return 1; }
+
+API void sacamd_default_cfg(sacamd_cfg *cfg) {
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->optimize = 0; cfg->sparse_pcm = 1; cfg->zero_mean = 1; cfg->reset = 0; cfg->fraction = 0; cfg->maxnfunc = 0;
+  cfg->num_threads = 0; cfg->sigma = 0.2; cfg->optk = 4; cfg->optimize_cost = SACAMD_COST_ENTROPY;
+}
+
+API int sacamd_default_profile(float *vmin, float *vmax, float *vdef) {
+  Coef c[kNumCoefs];
+  load_base_profile(c);
+  for (int i = 0; i < kNumCoefs; i++) { if (vmin) vmin[i] = c[i].vmin; if (vmax) vmax[i] = c[i].vmax; if (vdef) vdef[i] = c[i].vdef; }
+  return kNumCoefs;
+}
+
+API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames, sacamd_ctx **out) {
+  if (!out) return SACAMD_ERR_ARG;
+  *out = nullptr;
+  if (nch < 1 || nch > 2 || max_framesize < 1 || max_frames < 1) return SACAMD_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SACAMD_ERR_NOGPU;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SACAMD_ERR_NOGPU;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SACAMD_ERR_NOGPU;   // kernels are built for gfx950 only
+  if (hipSetDevice(device) != hipSuccess) return SACAMD_ERR_NOGPU;
+  sacamd_ctx *c = new sacamd_ctx();
+  c->device = device; c->nch = nch; c->max_framesize = max_framesize; c->max_frames = max_frames;
+  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
+  c->ch_stride = ((long long)max_framesize + 63) / 64 * 64;
+  c->frame_stride = c->ch_stride * nch;
+  const size_t tot = (size_t)c->frame_stride * max_frames;
+  if (c->d_pcm.ensure(tot) != hipSuccess || c->d_nsamp.ensure(max_frames) != hipSuccess ||
+      c->d_stats.ensure((size_t)max_frames * nch) != hipSuccess || c->d_frame_off.ensure(max_frames) != hipSuccess) {
+    sacamd_ctx_destroy(c);
+    return SACAMD_ERR_HIP;
+  }
+  *out = c;
+  return 0;
+}
+
+API void sacamd_ctx_destroy(sacamd_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); (void)hipStreamDestroy(c->stream); }
+  c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_raw16.release(); c->d_frame_off.release();
+  c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
+  c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_cost.release();
+  c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
+  c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
+  c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();
+  delete c;
+}
+
+API const char *sacamd_last_error(const sacamd_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+// ================================================================== (1) staging
+static int stage_common(sacamd_ctx *c, int nframes, int framesize, const int *numsamples) {
+  if (!c || nframes < 1 || nframes > c->max_frames || !numsamples) return fail(c, SACAMD_ERR_ARG, "bad frame count");
+  for (int f = 0; f < nframes; f++)
+    if (numsamples[f] < 1 || numsamples[f] > c->max_framesize) return fail(c, SACAMD_ERR_ARG, "numsamples outside [1,max_framesize]");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->nframes = nframes; c->framesize = framesize;
+  c->nsamp.assign(numsamples, numsamples + nframes);
+  c->analysed = c->final_done = c->encoded = false;
+  HIPCHK(c, hipMemcpyAsync(c->d_nsamp.p, numsamples, sizeof(int) * nframes, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+API int sacamd_frames_upload_i32(sacamd_ctx *c, int nframes, int framesize, const int32_t *pcm, long long fs, long long cs, const int *numsamples) {
+  if (!c || !pcm) return SACAMD_ERR_ARG;
+  int r = stage_common(c, nframes, framesize, numsamples);
+  if (r) return r;
+  HIPCHK(c, c->d_raw32.ensure((size_t)c->frame_stride * nframes));
+  for (int f = 0; f < nframes; f++)
+    for (int ch = 0; ch < c->nch; ch++)
+      HIPCHK(c, hipMemcpyAsync(c->d_raw32.p + f * c->frame_stride + ch * c->ch_stride, pcm + f * fs + ch * cs,
+                               sizeof(int) * numsamples[f], hipMemcpyDefault, c->stream));
+  c->raw_kind = 1; c->raw_fs = c->frame_stride; c->raw_cs = c->ch_stride;
+  return sync_stream(c);
+}
+
+static int stage_s16(sacamd_ctx *c, int nframes, int framesize, const long long *frame_offset, const int *numsamples) {
+  int r = stage_common(c, nframes, framesize, numsamples);
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(c->d_frame_off.p, frame_offset, sizeof(long long) * nframes, hipMemcpyHostToDevice, c->stream));
+  c->raw_kind = 2;
+  return 0;
+}
+
+API int sacamd_frames_upload_s16(sacamd_ctx *c, int nframes, int framesize, const int16_t *pcm, const long long *frame_offset, const int *numsamples) {
+  if (!c || !pcm || !frame_offset) return SACAMD_ERR_ARG;
+  int r = stage_s16(c, nframes, framesize, frame_offset, numsamples);
+  if (r) return r;
+  long long total = 0;
+  for (int f = 0; f < nframes; f++) total = std::max(total, frame_offset[f] + numsamples[f]);
+  HIPCHK(c, c->d_raw16.ensure((size_t)total * c->nch));
+  HIPCHK(c, hipMemcpyAsync(c->d_raw16.p, pcm, sizeof(int16_t) * total * c->nch, hipMemcpyDefault, c->stream));
+  c->attached16 = c->d_raw16.p;
+  return sync_stream(c);
+}
+
+API int sacamd_frames_attach_s16_device(sacamd_ctx *c, int nframes, int framesize, const int16_t *d_pcm, const long long *frame_offset, const int *numsamples) {
+  if (!c || !d_pcm || !frame_offset) return SACAMD_ERR_ARG;
+  int r = stage_s16(c, nframes, framesize, frame_offset, numsamples);
+  if (r) return r;
+  c->attached16 = d_pcm;
+  return sync_stream(c);
+}
+
+// ================================================================== (2) analyse
+API int sacamd_analyse(sacamd_ctx *c, const sacamd_cfg *cfg) {
+  if (!c || !cfg) return SACAMD_ERR_ARG;
+  if (c->nframes < 1 || !c->raw_kind) return fail(c, SACAMD_ERR_STATE, "no frames staged");
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned char *used = nullptr;
+  if (cfg->sparse_pcm) {
+    const size_t ub = (size_t)c->nframes * c->nch * 65540;
+    HIPCHK(c, c->d_used.ensure(ub));
+    HIPCHK(c, hipMemsetAsync(c->d_used.p, 0, ub, c->stream));
+    used = c->d_used.p;
+  }
+  {
+    Span sp(c, FAM_ANALYSE);
+    if (c->raw_kind == 1)
+      launch_analyse_i32(c->stream, c->nframes, c->nch, c->d_raw32.p, c->raw_fs, c->raw_cs, c->d_nsamp.p, cfg->zero_mean, c->d_pcm.p,
+                         c->frame_stride, c->ch_stride, c->d_stats.p, used);
+    else
+      launch_analyse_s16(c->stream, c->nframes, c->nch, c->attached16, c->d_frame_off.p, c->d_nsamp.p, cfg->zero_mean, c->d_pcm.p,
+                         c->frame_stride, c->ch_stride, c->d_stats.p, used);
+  }
+  c->h_stats.resize((size_t)c->nframes * c->nch);
+  HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats.p, sizeof(FrameStatsD) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
+  int r = sync_stream(c);
+  if (r) return r;
+  c->analysed = true; c->final_done = c->encoded = false;
+  return 0;
+}
+
+API int sacamd_get_stats(sacamd_ctx *c, int32_t *out) {
+  if (!c || !out) return SACAMD_ERR_ARG;
+  if (!c->analysed) return fail(c, SACAMD_ERR_STATE, "analyse first");
+  for (size_t i = 0; i < c->h_stats.size(); i++) {
+    out[4 * i] = c->h_stats[i].mean; out[4 * i + 1] = c->h_stats[i].minval; out[4 * i + 2] = c->h_stats[i].maxval; out[4 * i + 3] = c->h_stats[i].numsamples;
+  }
+  return 0;
+}
+
+// ================================================================== costs
+namespace {
+int run_costs(sacamd_ctx *c, int kind, const std::vector<long long> &off, const std::vector<int> &n, const int *d_err, std::vector<double> &out) {
+  const int count = (int)off.size();
+  out.assign(count, 0.0);
+  if (!count) return 0;
+  if (kind < 0 || kind > 3) return fail(c, SACAMD_ERR_ARG, "cost kind not available on this path");
+  HIPCHK(c, c->d_off.ensure(count)); HIPCHK(c, c->d_n.ensure(count)); HIPCHK(c, c->d_cost.ensure(count));
+  if (kind == 2) HIPCHK(c, c->d_hist.ensure((size_t)count * cost_hist_scratch_ints()));
+  HIPCHK(c, hipMemcpyAsync(c->d_off.p, off.data(), sizeof(long long) * count, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_n.p, n.data(), sizeof(int) * count, hipMemcpyHostToDevice, c->stream));
+  { Span sp(c, FAM_COST); launch_cost(c->stream, kind, d_err, c->d_off.p, c->d_n.p, count, c->d_hist.p, c->d_cost.p); }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out.data(), c->d_cost.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  return sync_stream(c);
+}
+}  // namespace
+
+// ================================================================== (3) evaluate
+API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const int *cand_frame, const float *coefs, double *costs) {
+  if (!c || !cfg || ncand < 0 || (ncand && (!cand_frame || !coefs || !costs))) return SACAMD_ERR_ARG;
+  if (!c->analysed) return fail(c, SACAMD_ERR_STATE, "analyse first");
+  if (!ncand) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<Cand> cands(ncand);
+  for (int i = 0; i < ncand; i++) {
+    if (cand_frame[i] < 0 || cand_frame[i] >= c->nframes) return fail(c, SACAMD_ERR_ARG, "candidate frame out of range");
+    int st, no;
+    search_window(c, cfg, cand_frame[i], &st, &no);
+    cands[i] = Cand{cand_frame[i], coefs + (size_t)i * kNumCoefs, st, no, true, cfg->optk};
+  }
+  std::vector<WorkItem> items;
+  int r = build_items(c, cands, items);
+  if (r) return r;
+  r = run_predict(c, items, false);
+  if (r) return r;
+  std::vector<long long> off(items.size());
+  std::vector<int> n(items.size());
+  for (size_t i = 0; i < items.size(); i++) { off[i] = items[i].off_err; n[i] = items[i].n; }
+  std::vector<double> cv;
+  if (cfg->optimize_cost == SACAMD_COST_BITPLANE) return fail(c, SACAMD_ERR_ARG, "bitplane search cost: use sacamd_encode_frames path");
+  r = run_costs(c, cfg->optimize_cost, off, n, c->d_err.p, cv);
+  if (r) return r;
+  // GetCost: sum over file channels 0,1 (libsac.cpp:355-361)
+  for (int i = 0; i < ncand; i++) {
+    double per_ch[2] = {0, 0};
+    for (int s = 0; s < c->nch; s++) per_ch[items[(size_t)i * c->nch + s].ch_self] = cv[(size_t)i * c->nch + s];
+    double cost = 0.0;
+    for (int ch = 0; ch < c->nch; ch++) cost += per_ch[ch];
+    if (!std::isfinite(cost)) cost = INFINITY;
+    costs[i] = cost;
+  }
+  return 0;
+}
+
+// ================================================================== (4) final pass
+API int sacamd_predict_final(sacamd_ctx *c, const sacamd_cfg *cfg, const float *coefs) {
+  if (!c || !cfg || !coefs) return SACAMD_ERR_ARG;
+  if (!c->analysed) return fail(c, SACAMD_ERR_STATE, "analyse first");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<Cand> cands(c->nframes);
+  for (int f = 0; f < c->nframes; f++) cands[f] = Cand{f, coefs + (size_t)f * kNumCoefs, 0, c->nsamp[f], false, cfg->optk};
+  std::vector<WorkItem> items;
+  int r = build_items(c, cands, items);
+  if (r) return r;
+  r = run_predict(c, items, true);
+  if (r) return r;
+  // scatter into per-(frame,channel) planes and S2U
+  const size_t tot = (size_t)c->frame_stride * c->nframes;
+  HIPCHK(c, c->d_ferr.ensure(tot)); HIPCHK(c, c->d_fpred.ensure(tot)); HIPCHK(c, c->d_fs2u.ensure(tot));
+  HIPCHK(c, c->d_maxbpn.ensure((size_t)c->nframes * c->nch));
+  std::vector<long long> off((size_t)c->nframes * c->nch);
+  std::vector<int> nn((size_t)c->nframes * c->nch);
+  for (auto &it : items) {
+    const long long dst = it.frame * c->frame_stride + it.ch_self * c->ch_stride;
+    HIPCHK(c, hipMemcpyAsync(c->d_ferr.p + dst, c->d_err.p + it.off_err, sizeof(int) * it.n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_fpred.p + dst, c->d_pred.p + it.off_err, sizeof(int) * it.n, hipMemcpyDeviceToDevice, c->stream));
+    off[(size_t)it.frame * c->nch + it.ch_self] = dst;
+    nn[(size_t)it.frame * c->nch + it.ch_self] = it.n;
+  }
+  HIPCHK(c, c->d_off.ensure(off.size())); HIPCHK(c, c->d_n.ensure(nn.size()));
+  HIPCHK(c, hipMemcpyAsync(c->d_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_n.p, nn.data(), sizeof(int) * nn.size(), hipMemcpyHostToDevice, c->stream));
+  { Span sp(c, FAM_S2U); launch_s2u(c->stream, c->d_ferr.p, c->d_fs2u.p, c->d_off.p, c->d_n.p, (int)off.size(), c->d_maxbpn.p); }
+  c->h_maxbpn.resize(off.size());
+  HIPCHK(c, hipMemcpyAsync(c->h_maxbpn.data(), c->d_maxbpn.p, sizeof(int) * off.size(), hipMemcpyDeviceToHost, c->stream));
+  r = sync_stream(c);
+  if (r) return r;
+  c->final_coefs.assign(coefs, coefs + (size_t)c->nframes * kNumCoefs);
+  c->final_done = true; c->encoded = false;
+  return 0;
+}
+
+API int sacamd_get_residuals(sacamd_ctx *c, int frame, int32_t *error, int32_t *pred, int32_t *s2u, int *maxbpn) {
+  if (!c || frame < 0 || frame >= c->nframes) return SACAMD_ERR_ARG;
+  if (!c->final_done) return fail(c, SACAMD_ERR_STATE, "predict_final first");
+  const int n = c->nsamp[frame];
+  for (int ch = 0; ch < c->nch; ch++) {
+    const long long src = frame * c->frame_stride + ch * c->ch_stride;
+    if (error) HIPCHK(c, hipMemcpy(error + (size_t)ch * n, c->d_ferr.p + src, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (pred) HIPCHK(c, hipMemcpy(pred + (size_t)ch * n, c->d_fpred.p + src, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (s2u) HIPCHK(c, hipMemcpy(s2u + (size_t)ch * n, c->d_fs2u.p + src, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (maxbpn) maxbpn[ch] = c->h_maxbpn[(size_t)frame * c->nch + ch];
+  }
+  return 0;
+}
+
+// ================================================================== parity taps
+API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int start, int n, int optimize, int optk,
+                             double *plpc, double *psum, int32_t *err, int32_t *pred) {
+  if (!c || !coefs || frame < 0 || frame >= c->nframes) return SACAMD_ERR_ARG;
+  if (!c->analysed) return fail(c, SACAMD_ERR_STATE, "analyse first");
+  if (start < 0 || n < 1 || start + n > c->nsamp[frame]) return fail(c, SACAMD_ERR_ARG, "window outside frame");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<Cand> cands{Cand{frame, coefs, start, n, optimize != 0, optk}};
+  std::vector<WorkItem> items;
+  int r = build_items(c, cands, items);
+  if (r) return r;
+  // stage by stage so the OLS stream can be captured before the cascade overwrites it
+  const int count = (int)items.size();
+  long long tot_tab = 0;
+  for (auto &it : items) for (int s = 0; s < 4; s++) tot_tab += 2LL * it.p.vn[s];
+  HIPCHK(c, c->d_items.ensure(count)); HIPCHK(c, c->d_p.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_err.ensure((size_t)n * count + 512));
+  HIPCHK(c, c->d_pred.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16)); HIPCHK(c, c->d_idx.ensure(count + 16));
+  HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
+  launch_tables(c->stream, c->d_items.p, count, c->d_tab.p);
+  for (int i = 0; i < count; i++) {
+    HIPCHK(c, hipMemcpyAsync(c->d_idx.p, &i, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (plpc) HIPCHK(c, hipMemcpy(plpc + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, view(c), c->d_tab.p, c->d_p.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, c->d_pred.p);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  for (int i = 0; i < count; i++) {
+    if (err) HIPCHK(c, hipMemcpy(err + (size_t)items[i].ch_self * n, c->d_err.p + items[i].off_err, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (pred) HIPCHK(c, hipMemcpy(pred + (size_t)items[i].ch_self * n, c->d_pred.p + items[i].off_err, sizeof(int) * n, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+API int sacamd_debug_cost(sacamd_ctx *c, int kind, const int32_t *err, int n, double *cost) {
+  if (!c || !err || !cost || n < 0) return SACAMD_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_err.ensure((size_t)n + 16));
+  HIPCHK(c, hipMemcpy(c->d_err.p, err, sizeof(int) * n, hipMemcpyHostToDevice));
+  std::vector<long long> off{0};
+  std::vector<int> nn{n};
+  std::vector<double> out;
+  int r = run_costs(c, kind, off, nn, c->d_err.p, out);
+  if (r) return r;
+  *cost = out[0];
+  return 0;
+}
+
+API int sacamd_kernel_times(sacamd_ctx *c, double *out16, int reset) {
+  if (!c || !out16) return SACAMD_ERR_ARG;
+  for (int i = 0; i < 8; i++) { out16[i] = i < FAM_COUNT ? c->fam_ms[i] : 0.0; out16[8 + i] = i < FAM_COUNT ? (double)c->fam_launches[i] : 0.0; }
+  if (reset) for (int i = 0; i < FAM_COUNT; i++) { c->fam_ms[i] = 0; c->fam_launches[i] = 0; }
+  return 0;
+}
+
+#include "host_encode.inc"

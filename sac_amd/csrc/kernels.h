@@ -1,0 +1,54 @@
+// sac_amd/csrc/kernels.h -- launch wrappers of the HIP kernels (definitions in kernels_*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "params.h"
+
+namespace sacamd {
+
+struct PcmView {            // centred planar int32 PCM of the staged batch
+  const int *pcm;
+  long long frame_stride, ch_stride;
+};
+
+// ---- analyse (kernels_misc.hip)
+void launch_analyse_s16(hipStream_t s, int nframes, int nch, const int16_t *d_il, const long long *d_frame_off,
+                        const int *d_nsamp, int zero_mean, int *d_pcm, long long frame_stride, long long ch_stride,
+                        FrameStatsD *d_stats, unsigned char *d_used /*nullable [f][ch][65537]*/);
+void launch_analyse_i32(hipStream_t s, int nframes, int nch, const int *d_raw, long long raw_fs, long long raw_cs,
+                        const int *d_nsamp, int zero_mean, int *d_pcm, long long frame_stride, long long ch_stride,
+                        FrameStatsD *d_stats, unsigned char *d_used);
+// ---- predictor stages (kernels_pred.hip)
+void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab);
+void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p);
+void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, PcmView v,
+                const double *d_tab, double *d_p);
+void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
+                 const double *d_p, int *d_err, int *d_pred /*nullable*/);
+// ---- costs / s2u (kernels_misc.hip)
+void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_off, const int *d_n, int count,
+                 int *d_hist_scratch, double *d_cost);
+void launch_s2u(hipStream_t s, const int *d_err, int *d_s2u, const long long *d_off, const int *d_n, int count, int *d_maxbpn);
+size_t cost_hist_scratch_ints();
+// ---- coder (kernels_coder.hip)
+struct CoderJob {
+  long long off_in;     // ints into d_s2u
+  long long off_out;    // bytes into d_out
+  int n, maxbpn;
+  int cap;              // output capacity in bytes
+  int with_map;         // 1: MapEncoder prefix over used flags
+  long long off_used;   // bytes into d_used (usedl at +0 .. usedh at +32769)
+};
+void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const unsigned char *d_used,
+                  const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv,
+                  unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len);
+size_t coder_state_bytes();
+struct RemapJob {
+  long long off;        // ints into pred / err / s2u_map planes
+  long long off_used;   // bytes into d_used
+  int n;
+};
+void launch_remap(hipStream_t s, const RemapJob *d_jobs, int count, const unsigned char *d_used, const int *d_pred, const int *d_err,
+                  int *d_s2u_map, int *d_prefix_scratch, long long *d_out3);
+
+}  // namespace sacamd

@@ -1,0 +1,111 @@
+// sac_amd/csrc/kernels_coder.hip -- gfx950 kernels: bitplane/SSE range coder streams and the
+// sparse-PCM residual remap (Remap::Map + CalcRemapError, map.cpp:175-187, libsac.cpp:230-251).
+#include "coder.h"
+#include "kernels.h"
+
+namespace sacamd {
+
+struct CoderLdsLayout {
+  static constexpr size_t o_fwd = 0;
+  static constexpr size_t o_inv = o_fwd + sizeof(short) * kPScale;
+  static constexpr size_t o_model = o_inv + sizeof(unsigned short) * 4096;
+  static constexpr size_t o_desc = (o_model + sizeof(CoderModel) + 15) / 16 * 16;
+  static constexpr size_t o_win = (o_desc + sizeof(CoderDesc) + 15) / 16 * 16;
+  static constexpr size_t o_map = (o_win + sizeof(CoderWin) + 15) / 16 * 16;
+  static constexpr size_t total = (o_map + sizeof(MapModel) + 15) / 16 * 16;
+};
+
+size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
+
+__global__ __launch_bounds__(64) void k_coder(const CoderJob *jobs, const int *s2u, const unsigned char *used, const unsigned short *laplace,
+                                               const short *gfwd, const unsigned short *ginv, unsigned char *state, size_t stride,
+                                               unsigned char *out, int *len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const CoderJob job = jobs[blockIdx.x];
+  short *fwd = reinterpret_cast<short *>(smem + CoderLdsLayout::o_fwd);
+  unsigned short *inv = reinterpret_cast<unsigned short *>(smem + CoderLdsLayout::o_inv);
+  CoderModel &M = *reinterpret_cast<CoderModel *>(smem + CoderLdsLayout::o_model);
+  CoderDesc &D = *reinterpret_cast<CoderDesc *>(smem + CoderLdsLayout::o_desc);
+  CoderWin &W = *reinterpret_cast<CoderWin *>(smem + CoderLdsLayout::o_win);
+  MapModel &MM = *reinterpret_cast<MapModel *>(smem + CoderLdsLayout::o_map);
+  CntL *csig0 = reinterpret_cast<CntL *>(state + (size_t)blockIdx.x * stride);
+  const unsigned short *plap = laplace + (size_t)kLaplacePlanes * kLaplaceAvg;
+  ExecDev<64> ex;
+  const int l = coder_stream(ex, s2u + job.off_in, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace, gfwd, ginv,
+                             plap, csig0, out + job.off_out, job.cap, M, D, W, MM, fwd, inv);
+  if (threadIdx.x == 0) len[blockIdx.x] = l;
+}
+
+void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const unsigned char *d_used,
+                  const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv, unsigned char *d_state,
+                  size_t state_stride, unsigned char *d_out, int *d_len) {
+  if (count <= 0) return;
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::total); once = true; }
+  hipLaunchKernelGGL(k_coder, dim3(count), dim3(64), CoderLdsLayout::total, s, d_jobs, d_s2u, d_used, d_laplace, d_fwd, d_inv, d_state,
+                     state_stride, d_out, d_len);
+}
+
+// ------------------------------------------------------------------ remap
+// grid: one block (256) per (frame,channel) job.  prefix scratch: 65540 ints per job.
+__device__ __forceinline__ int used_flag(const unsigned char *u, int v) {
+  if (v == 0) return 1;
+  return v > 0 ? u[32769 + v] : u[-v];
+}
+
+__global__ __launch_bounds__(256) void k_remap(const RemapJob *jobs, const unsigned char *used, const int *pred, const int *err, int *s2u_map,
+                                                int *prefix_scratch, long long *out3) {
+  __shared__ int part[256];
+  __shared__ long long s_ll[4];
+  __shared__ int s_i[4];
+  const RemapJob job = jobs[blockIdx.x];
+  const unsigned char *u = used + job.off_used;
+  int *prefix = prefix_scratch + (size_t)blockIdx.x * 65540;
+  // prefix[j] = #used values in [-32768, -32768 + j - 1], j = 0..65537
+  constexpr int N = 65537, PER = (N + 255) / 256;
+  const int j0 = threadIdx.x * PER, j1 = (j0 + PER < N) ? j0 + PER : N;
+  int loc = 0;
+  for (int j = j0; j < j1; j++) loc += used_flag(u, j - 32768);
+  part[threadIdx.x] = loc;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; i++) { const int t = part[i]; part[i] = run; run += t; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int j = j0; j < j1; j++) { prefix[j] = run; run += used_flag(u, j - 32768); }
+  if (j1 == N && j0 < N) prefix[N] = run;
+  __syncthreads();
+  auto cnt = [&](int a, int b) {
+    a = a < -32768 ? -32768 : a; b = b > 32768 ? 32768 : b;
+    return a > b ? 0 : prefix[b + 32768 + 1] - prefix[a + 32768];
+  };
+  const int *p = pred + job.off, *e = err + job.off;
+  int *um = s2u_map + job.off;
+  long long se = 0, sm = 0; int mx = 0;
+  for (int i = threadIdx.x; i < job.n; i += 256) {
+    const int ev = e[i], pv = p[i];
+    int m = 0;
+    if (ev > 0) m = cnt(pv + 1, pv + ev); else if (ev < 0) m = -cnt(pv + ev, pv - 1);
+    const int v = m < 0 ? 2 * (-m) : (m > 0 ? 2 * m - 1 : 0);
+    um[i] = v;
+    se += ev < 0 ? -(long long)ev : ev; sm += m < 0 ? -(long long)m : m; mx = v > mx ? v : mx;
+  }
+  // block reductions (butterfly + waves in order)
+  for (int d = 32; d >= 1; d >>= 1) { se += __shfl_xor(se, d, 64); sm += __shfl_xor(sm, d, 64); const int o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
+  const int w = threadIdx.x >> 6;
+  __shared__ long long s_ll2[4];
+  if ((threadIdx.x & 63) == 0) { s_ll[w] = se; s_ll2[w] = sm; s_i[w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long a = 0, b = 0; int m = 0;
+    for (int i = 0; i < 4; i++) { a += s_ll[i]; b += s_ll2[i]; m = s_i[i] > m ? s_i[i] : m; }
+    out3[3 * blockIdx.x] = a; out3[3 * blockIdx.x + 1] = b; out3[3 * blockIdx.x + 2] = m;
+  }
+}
+
+void launch_remap(hipStream_t s, const RemapJob *d_jobs, int count, const unsigned char *d_used, const int *d_pred, const int *d_err,
+                  int *d_s2u_map, int *d_prefix_scratch, long long *d_out3) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_remap, dim3(count), dim3(256), 0, s, d_jobs, d_used, d_pred, d_err, d_s2u_map, d_prefix_scratch, d_out3);
+}
+
+}  // namespace sacamd

@@ -1,0 +1,122 @@
+// sac_amd/csrc/kernels_pred.hip -- gfx950 kernels of the three predictor stages.
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fma only; see canon.h).
+#include "kernels.h"
+#include "pred_bias.h"
+#include "pred_lms.h"
+#include "pred_ols.h"
+#include "pred_tables.h"
+
+namespace sacamd {
+
+// ------------------------------------------------------------------ NLMS tables
+// grid (work-item, stage); mutab/powtab per tap, then the in-order sum of powtab (ls.h:37-42)
+__global__ __launch_bounds__(256) void k_tables(WorkItem *items, double *tab) {
+  __shared__ double chunk[256];
+  WorkItem &it = items[blockIdx.x];
+  const int s = blockIdx.y;
+  long long off = it.off_tab;
+  for (int q = 0; q < s; q++) off += 2LL * it.p.vn[q];
+  const int ns = it.p.vn[s];
+  double *mt = tab + off, *pt = tab + off + ns;
+  const double mud = it.p.vmudecay[s], pwd = it.p.vpowdecay[s];
+  for (int i = threadIdx.x; i < ns; i += 256) {
+    double m, p;
+    lms_table_entry(i, mud, pwd, &m, &p);
+    mt[i] = m; pt[i] = p;
+  }
+  double sum = 0.0;
+  for (int b = 0; b < ns; b += 256) {
+    __syncthreads();
+    chunk[threadIdx.x] = (b + (int)threadIdx.x < ns) ? pt[b + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = ns - b < 256 ? ns - b : 256;
+      for (int i = 0; i < m; i++) sum += chunk[i];
+    }
+  }
+  if (threadIdx.x == 0) it.sum_powtab[s] = sum;
+}
+
+void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_tables, dim3(count, 4), dim3(256), 0, s, d_items, d_tab);
+}
+
+// ------------------------------------------------------------------ stage 1: OLS
+template <int NL, int NMAX>
+__global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WorkItem &it = items[idx[blockIdx.x]];
+  const ChanParam p = it.p;
+  const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+  const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
+  ExecDev<NL> ex;
+  ols_stage(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
+}
+
+void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p) {
+  if (count <= 0) return;
+  if (ols_class == 0) {
+    hipLaunchKernelGGL((k_ols<64, 32>), dim3(count), dim3(64), OlsLds::bytes(32), s, d_items, d_idx, v, d_p);
+  } else if (ols_class == 1) {
+    hipLaunchKernelGGL((k_ols<64, 64>), dim3(count), dim3(64), OlsLds::bytes(64), s, d_items, d_idx, v, d_p);
+  } else {
+    static bool once = false;
+    if (!once) { hipFuncSetAttribute((const void *)k_ols<128, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OlsLds::bytes(96)); once = true; }
+    hipLaunchKernelGGL((k_ols<128, 96>), dim3(count), dim3(128), OlsLds::bytes(96), s, d_items, d_idx, v, d_p);
+  }
+}
+
+// ------------------------------------------------------------------ stage 2: cascade
+template <class C>
+__global__ __launch_bounds__(256) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, double *pbuf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WorkItem &it = items[idx[blockIdx.x]];
+  const ChanParam p = it.p;
+  double sp[4];
+  for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
+  const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+  ExecDev<256> ex;
+  lms_stage<ExecDev<256>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem);
+}
+
+template <class C>
+static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, const double *d_tab, double *d_p) {
+  static bool once = false;
+  const size_t bytes = LmsLds<256, C>::bytes();
+  if (!once) { hipFuncSetAttribute((const void *)k_lms<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); once = true; }
+  hipLaunchKernelGGL((k_lms<C>), dim3(count), dim3(256), bytes, s, d_items, d_idx, v, d_tab, d_p);
+}
+
+void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, PcmView v,
+                const double *d_tab, double *d_p) {
+  if (count <= 0) return;
+  if (lms_class == 0) launch_lms_c<LmsClass<8, 4, 2, 1>>(s, d_items, d_idx, count, v, d_tab, d_p);
+  else if (lms_class == 1) launch_lms_c<LmsClass<16, 8, 4, 2>>(s, d_items, d_idx, count, v, d_tab, d_p);
+  else launch_lms_c<LmsClass<32, 16, 8, 4>>(s, d_items, d_idx, count, v, d_tab, d_p);
+}
+
+// ------------------------------------------------------------------ stage 3: bias + residual
+constexpr int kBiasSlabStride = kBiasSlabDoubles + 1;   // odd stride: spread lanes over LDS banks
+
+__global__ __launch_bounds__(64) void k_bias(const WorkItem *items, int count, PcmView v, const FrameStatsD *stats, int nch,
+                                              const double *pbuf, int *errbuf, int *predbuf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= count) return;
+  const WorkItem &it = items[i];
+  const ChanParam p = it.p;
+  const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+  double *tables = reinterpret_cast<double *>(smem) + (size_t)threadIdx.x * kBiasSlabStride;
+  const int mean = stats[it.frame * nch + it.ch_self].mean;
+  bias_stage(p, self, it.n, pbuf + it.off_p, mean, errbuf + it.off_err, predbuf ? predbuf + it.off_err : nullptr, tables);
+}
+
+void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
+                 const double *d_p, int *d_err, int *d_pred) {
+  if (count <= 0) return;
+  const size_t bytes = (size_t)64 * kBiasSlabStride * sizeof(double);
+  hipLaunchKernelGGL(k_bias, dim3((count + 63) / 64), dim3(64), bytes, s, d_items, count, v, d_stats, nch, d_p, d_err, d_pred);
+}
+
+}  // namespace sacamd

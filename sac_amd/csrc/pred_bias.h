@@ -1,0 +1,88 @@
+// sac_amd/csrc/pred_bias.h -- stage 3 of the predictor: bias correction + residual.
+//
+// Reference: BiasEstimator (/root/reference/src/pred/bias.h:16-175) with its SSLMS mixers
+// (pred/ls.h:279-292) and RunMeanVar (common/utils.h:75-110), then the rounding/clamping of
+// FrameCoder::PredictFrame's eprocess lambda (libsac/libsac.cpp:104-110).
+//
+// Input is the p_lpc+p_lms stream of stage 2 plus the PCM; it is a ~150-operation scalar
+// recurrence per sample, so one LANE runs one work-item (64 work-items per wave); the three
+// context tables (32+8+16 entries of {cnt,val}) sit in LDS, one private slab per lane.
+#pragma once
+#include "canon.h"
+#include "params.h"
+
+namespace sacamd {
+
+constexpr int kBiasCtx = 56;                       // 32 (ctx0) + 8 (ctx1) + 16 (ctx2)
+constexpr int kBiasSlabDoubles = 2 * kBiasCtx;     // {cnt,val} pairs
+
+// tables: this lane's slab of kBiasSlabDoubles doubles.  err/pred may be null.
+SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *psum, int mean,
+                      int *err, int *pred, double *tables) {
+  double *cnt = tables, *val = tables + kBiasCtx;
+  for (int i = 0; i < kBiasCtx; i++) { cnt[i] = 4.0; val[i] = 0.0; }
+  double mixw[4][3];
+  for (int a = 0; a < 4; a++) for (int b = 0; b < 3; b++) mixw[a][b] = 0.0;
+  double hin0 = 0, hin1 = 0, hin2 = 0;
+  double hd0 = 0, hd1 = 0, hd2 = 0, hd3 = 0, hd4 = 0;
+  double rmean = 0.0, rvar = 0.0;
+  const double nscale = (double)(1 << p.bias_scale);
+  const double mu = p.bias_mu;
+
+  for (int t = 0; t < n; t++) {
+    const double px = psum[t];
+    // CalcContext (bias.h:64-113)
+    const int b0 = hin0 > px ? 0 : 1;
+    const int b2 = hd0 < 0 ? 0 : 1, b3 = hd1 < 0 ? 0 : 1, b4 = hd2 < 0 ? 0 : 1;
+    const int b5 = hd1 < hd0 ? 0 : 1, b6 = hd2 < hd1 ? 0 : 1, b7 = hd3 < hd2 ? 0 : 1, b8 = hd4 < hd3 ? 0 : 1;
+    const int b9 = fabs(hd0) > 32 ? 0 : 1;
+    const int b10 = 2 * hin0 - hin1 > px ? 0 : 1;
+    const int b11 = 3 * hin0 - 3 * hin1 + hin2 > px ? 0 : 1;
+    double sum = 0;
+    sum += fabs(hd0); sum += fabs(hd1); sum += fabs(hd2); sum += fabs(hd3); sum += fabs(hd4);
+    sum /= 5.0;
+    int mix_ctx = 0;
+    if (sum > 512) mix_ctx = 2; else if (sum > 32) mix_ctx = 1;
+    const int c0 = b0 + (b2 << 1) + (b9 << 2) + (b10 << 3) + (b11 << 4);
+    const int c1 = 32 + b2 + (b3 << 1) + (b4 << 2);
+    const int c2 = 40 + b5 + (b6 << 1) + (b7 << 2) + (b8 << 3);
+    // Predict (bias.h:114-126)
+    double pt[3];
+    pt[0] = val[c0] / cnt[c0];
+    pt[1] = val[c1] / cnt[c1];
+    pt[2] = val[c2] / cnt[c2];
+    double *mw = mixw[mix_ctx];
+    const double pbias = dot_canon(pt, mw, 3);
+    const double pd = px + pbias;
+    // eprocess (libsac.cpp:105-109)
+    const int v = self[t];
+    const int pi = clampi32((int)round(pd), p.out_lo, p.out_hi);
+    if (pred) pred[t] = pi + mean;
+    if (err) err[t] = v - pi;
+    // Update (bias.h:127-163)
+    const double dv = (double)v;
+    const double delta = dv - round(px);
+    hin2 = hin1; hin1 = hin0; hin0 = dv;
+    hd4 = hd3; hd3 = hd2; hd2 = hd1; hd1 = hd0; hd0 = delta;
+    const double var0 = fmax(0.0, rvar);
+    const double diff = delta - rmean;
+    const double z = diff * diff / (var0 + 1E-5);
+    const double w = exp(-0.5 * z);
+    const int cc[3] = {c0, c1, c2};
+    for (int q = 0; q < 3; q++) {
+      const int c = cc[q];
+      double vv = val[c] + w * delta;      // not fused in the reference binary
+      double cn = cnt[c] + w;
+      if (cn >= nscale) { vv *= 0.5; cn *= 0.5; }
+      val[c] = vv; cnt[c] = cn;
+    }
+    const double a = 0.998;
+    const double old_mean = rmean;
+    rmean = fma(a, rmean, (1.0 - a) * delta);
+    rvar = fma(a, rvar, (1.0 - a) * ((delta - old_mean) * (delta - rmean)));
+    const double wf = mu * sgnd(delta - pbias);
+    for (int i = 0; i < 3; i++) mw[i] = fma(wf, sgnd(pt[i]), mw[i]);
+  }
+}
+
+}  // namespace sacamd

@@ -1,0 +1,115 @@
+// sac_amd/csrc/simt.h -- minimal SIMT executor abstraction.
+//
+// Kernel bodies are written once, as templates over an executor E:
+//   E::Reg<T> r;          per-lane register            r[lane]
+//   ex.par(f)             run f(lane) on every lane     (no implicit barrier)
+//   ex.sync()             workgroup barrier
+//   ex.allsum(r)          butterfly all-reduce within 64-lane waves, then waves in order
+//   ex.lane_get(r, k)     value of lane k's register (uniform k)
+// ExecDev<NL> maps this onto a real gfx950 workgroup of NL threads; ExecEmu<NL> (host only,
+// used by the CPU logic tests) runs the lanes one after another, with exactly the same
+// floating-point operation order, so the kernels' results can be checked without a GPU.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SA_HD __host__ __device__ __forceinline__
+#define SA_D __device__ __forceinline__
+#else
+#define SA_HD inline
+#endif
+
+namespace sacamd {
+
+// ------------------------------------------------------------------ emulation executor
+template <int NL>
+struct ExecEmu {
+  static constexpr int nl = NL;
+  static constexpr bool is_device = false;
+  template <class T> struct Reg {
+    T v[NL];
+    T &operator[](int l) { return v[l]; }
+    const T &operator[](int l) const { return v[l]; }
+  };
+  template <class F> void par(F &&f) { for (int l = 0; l < NL; l++) f(l); }
+  // code that every lane executes with identical (uniform) operands: run once
+  template <class F> void uni(F &&f) { f(); }
+  // code only wave 0 executes (uniformly): run once
+  template <class F> void leader(F &&f) { f(); }
+  void sync() {}
+  template <class T> T lane_get(const Reg<T> &r, int k) { return r[k]; }
+  // butterfly sum of K values per lane within each 64-lane wave (all lanes get the wave total)
+  template <int K, class R> void wave_sum(R &r) {
+    constexpr int W = NL < 64 ? NL : 64;
+    for (int q = 0; q < K; q++)
+      for (int d = W / 2; d >= 1; d >>= 1) {
+        double t[NL];
+        for (int l = 0; l < NL; l++) t[l] = r[l].v[q] + r[(l & ~(W - 1)) | ((l & (W - 1)) ^ d)].v[q];
+        for (int l = 0; l < NL; l++) r[l].v[q] = t[l];
+      }
+  }
+  // butterfly within waves of 64 (or NL if smaller), then sequential over waves
+  void allsum(Reg<double> &r, double *scratch /*>= NL/64 doubles*/) {
+    constexpr int W = NL < 64 ? NL : 64;
+    for (int d = W / 2; d >= 1; d >>= 1) {
+      double t[NL];
+      for (int l = 0; l < NL; l++) t[l] = r[l] + r[(l & ~(W - 1)) | ((l & (W - 1)) ^ d)];
+      for (int l = 0; l < NL; l++) r[l] = t[l];
+    }
+    if (NL > 64) {
+      double s = r[0];
+      for (int w = 1; w < NL / 64; w++) s = s + r[w * 64];
+      for (int l = 0; l < NL; l++) r[l] = s;
+    }
+    (void)scratch;
+  }
+};
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ device executor
+template <int NL>
+struct ExecDev {
+  static constexpr int nl = NL;
+  static constexpr bool is_device = true;
+  template <class T> struct Reg {
+    T v;
+    SA_D T &operator[](int) { return v; }
+    SA_D const T &operator[](int) const { return v; }
+  };
+  template <class F> SA_D void par(F &&f) { f((int)threadIdx.x); }
+  template <class F> SA_D void uni(F &&f) { f(); }
+  template <class F> SA_D void leader(F &&f) { if (threadIdx.x < 64) f(); }
+  SA_D void sync() { __syncthreads(); }
+  template <int K, class R> SA_D void wave_sum(R &r) {
+    constexpr int W = NL < 64 ? NL : 64;
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) {
+#pragma unroll
+      for (int q = 0; q < K; q++) r.v.v[q] = r.v.v[q] + __shfl_xor(r.v.v[q], d, 64);
+    }
+  }
+  template <class T> SA_D T lane_get(const Reg<T> &r, int k) { return __shfl(r.v, k, 64); }
+  SA_D void allsum(Reg<double> &r, double *scratch) {
+    constexpr int W = NL < 64 ? NL : 64;
+    double v = r.v;
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
+    if (NL > 64) {
+      const int w = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) scratch[w] = v;
+      __syncthreads();
+      double s = scratch[0];
+#pragma unroll
+      for (int i = 1; i < NL / 64; i++) s = s + scratch[i];
+      v = s;
+      __syncthreads();
+    }
+    r.v = v;
+  }
+};
+#endif
+
+}  // namespace sacamd

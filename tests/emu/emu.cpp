@@ -1,0 +1,92 @@
+// tests/emu/emu.cpp -- CPU execution of the *product's kernel bodies* (sac_amd/csrc/pred_*.h,
+// coder.h) through the lane-serial ExecEmu executor.  Test infrastructure only: lets the
+// `-m "not gpu"` suite check the kernels' logic (right-looking LDLT, fused NLMS sweep, ring
+// indexing, stereo geometry ...) against the oracle without a GPU.  The product never builds
+// or loads this file.
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+#include "../../sac_amd/csrc/pred_ols.h"
+#include "../../sac_amd/csrc/pred_lms.h"
+#include "../../sac_amd/csrc/pred_bias.h"
+#include "../../sac_amd/csrc/pred_tables.h"
+
+using namespace sacamd;
+#define API extern "C" __attribute__((visibility("default")))
+
+template <class C>
+static void run_lms(const ChanParam &p, const double *sp, const double *tab, const int *self, int n, double *pio) {
+  std::vector<char> lds(LmsLds<256, C>::bytes());
+  ExecEmu<256> ex;
+  lms_stage<ExecEmu<256>, C>(ex, p, sp, tab, self, n, pio, lds.data());
+}
+
+// samples planar [nch][total] mean-removed; stats [nch][3] = {min,max,mean}
+API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *stats, const float *coefs,
+                    int from, int n, int optimize, int optk, double *plpc, double *psum,
+                    int32_t *err, int32_t *pred) {
+  FrameStatsD st[2] = {};
+  for (int ch = 0; ch < nch; ch++) { st[ch].minval = stats[3 * ch]; st[ch].maxval = stats[3 * ch + 1]; st[ch].mean = stats[3 * ch + 2]; st[ch].numsamples = total; }
+  ChanParam cp[2]; int ch_ref = 0;
+  map_profile(coefs, optimize != 0, optk, nch, st, cp, &ch_ref);
+  for (int slot = 0; slot < nch; slot++) {
+    const int ch_self = (nch == 2) ? (slot == 0 ? ch_ref : 1 - ch_ref) : 0;
+    const int ch_other = (nch == 2) ? 1 - ch_self : 0;
+    const ChanParam &p = cp[slot];
+    const int32_t *self = samples + (size_t)ch_self * total + from;
+    const int32_t *other = samples + (size_t)ch_other * total + from;
+    double *pl = plpc + (size_t)ch_self * n, *ps = psum + (size_t)ch_self * n;
+    if (p.n_ols > kMaxOLS) return -1;
+    {
+      std::vector<char> lds(OlsLds::bytes(p.n_ols <= 64 ? 64 : 128));
+      if (p.n_ols <= 64) { ExecEmu<64> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 64); }
+      else { ExecEmu<128> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 128); }
+    }
+    std::vector<double> tab; double sp[4];
+    for (int s = 0; s < 4; s++) {
+      size_t o = tab.size(); tab.resize(o + 2 * (size_t)p.vn[s]);
+      double sum = 0;
+      for (int i = 0; i < p.vn[s]; i++) { lms_table_entry(i, p.vmudecay[s], p.vpowdecay[s], &tab[o + i], &tab[o + p.vn[s] + i]); sum += tab[o + p.vn[s] + i]; }
+      sp[s] = sum;
+    }
+    for (int t = 0; t < n; t++) ps[t] = pl[t];
+    const int *vn = p.vn;
+    if (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) run_lms<LmsClass<8, 4, 2, 1>>(p, sp, tab.data(), self, n, ps);
+    else if (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<16, 8, 4, 2>>(p, sp, tab.data(), self, n, ps);
+    else run_lms<LmsClass<32, 16, 8, 4>>(p, sp, tab.data(), self, n, ps);
+    std::vector<double> tables(kBiasSlabDoubles);
+    bias_stage(p, self, n, ps, stats[3 * ch_self + 2], err + (size_t)ch_self * n, pred ? pred + (size_t)ch_self * n : nullptr, tables.data());
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- coder
+#include "../../sac_amd/csrc/coder.h"
+#include <cmath>
+static void host_laplace(std::vector<unsigned short> &lap, unsigned short *plap) {
+  lap.resize((size_t)kLaplacePlanes * kLaplaceAvg);
+  for (int b = 0; b < kLaplacePlanes; b++)
+    for (int a = 0; a < kLaplaceAvg; a++) {
+      double p_l = 0.0;
+      if (a > 0) { double theta = std::exp(-1.0 / a); p_l = 1.0 - 1.0 / (1 + std::pow(theta, (double)(1 << b))); }
+      int p1 = std::min(std::max((int)std::round(p_l * kPScale), 1), (int)kPScaleM);
+      lap[(size_t)b * kLaplaceAvg + a] = (unsigned short)p1;
+    }
+  for (int i = 0; i < 32; i++) {
+    double pw = std::pow(0.99, (double)(i < 31 ? (1 << i) : -2147483647 - 1));
+    plap[i] = (unsigned short)std::min(std::max((int)std::round((1.0 - 1.0 / (1 + pw)) * kPScale), 1), (int)kPScaleM);
+  }
+}
+API int emu_bitplane(const int32_t *s2u, int n, int maxbpn, const unsigned char *used, const int *fwd_i, const int *inv_i, unsigned char *out, int cap) {
+  static std::vector<unsigned short> lap; static unsigned short plap[32];
+  if (lap.empty()) host_laplace(lap, plap);
+  std::vector<short> gf(kPScale), lf(kPScale); std::vector<unsigned short> gi(4095), li(4095);
+  for (int i = 0; i < kPScale; i++) gf[i] = (short)fwd_i[i];
+  for (int i = 0; i < 4095; i++) gi[i] = (unsigned short)inv_i[i];
+  std::vector<CntL> csig0(65536);
+  CoderModel *M = new CoderModel; CoderDesc *D = new CoderDesc; CoderWin *W = new CoderWin; MapModel *MM = new MapModel;
+  ExecEmu<64> ex;
+  int len = coder_stream(ex, s2u, n, maxbpn, used, lap.data(), gf.data(), gi.data(), plap, csig0.data(), out, cap, *M, *D, *W, *MM, lf.data(), li.data());
+  delete M; delete D; delete W; delete MM;
+  return len;
+}
