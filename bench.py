@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- SAC encode hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (analyse -> DDS search -> final prediction -> bitplane/SSE
+range coding -> frame records on the host [-> RCCL gather to rank 0]) over one batch of synthetic
+16-bit / 44.1 kHz stereo frames, `--high` preset (fraction 0.1, 100 evaluations, sigma 0.2,
+entropy cost) with the search run as 8-candidate DDS generations and --opt-reset
+(== reference `--high --opt-cfg=dds,8 --opt-reset`).  Inputs (interleaved int16 PCM) are resident
+in HBM before the timed region starts.  Frames shard across ranks with no data-path collective
+(weak scaling: every GPU gets --frames frames); the only collective is the final record gather.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+RATE = 44100
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# algorithmic HBM bytes per predictor channel-step of each stage kernel (DESIGN.md "Data layout")
+STAGE_BYTES = {"ols": 4 + 4 + 8,     # own + other-channel PCM (int32), p_lpc out (fp64)
+               "lms": 8 + 4 + 8,     # p_lpc in, PCM target, p_lpc+p_lms out
+               "bias": 8 + 4 + 4}    # p in, PCM, residual out
+
+
+def make_batch(nframes, seconds, seed0):
+    from sac_amd.synth import synth_pcm
+
+    n = int(seconds * RATE)
+    frames = [synth_pcm(n, 2, seed=seed0 + i, rate=RATE) for i in range(nframes)]
+    il = np.concatenate([f.T.astype(np.int16) for f in frames], axis=0)   # [nframes*n, 2] interleaved
+    return frames, np.ascontiguousarray(il), n
+
+
+def gather_records(recs, rank, world, device):
+    """Variable-length gather of frame records to rank 0 over RCCL (lengths, then padded payloads)."""
+    import torch
+    import torch.distributed as dist
+
+    blob = b"".join(recs)
+    lens = torch.tensor([len(r) for r in recs], dtype=torch.int64, device=device)
+    all_lens = [torch.zeros_like(lens) for _ in range(world)]
+    dist.all_gather(all_lens, lens)
+    tot = torch.tensor([len(blob)], dtype=torch.int64, device=device)
+    tots = [torch.zeros_like(tot) for _ in range(world)]
+    dist.all_gather(tots, tot)
+    mx = int(max(int(t.item()) for t in tots))
+    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+    buf[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    res = []
+    for r in range(world):
+        b = out[r][: int(tots[r].item())].cpu().numpy().tobytes()
+        o = 0
+        for ln in all_lens[r].tolist():
+            res.append(b[o: o + ln]); o += ln
+    return res
+
+
+def cpu_baseline(seconds=3.0, nthreads=8):
+    """Reference `--high --opt-cfg=dds,N --opt-reset` CPU encode on a bounded sample: one stereo
+    frame of `seconds` s with max frame length == `seconds` s, so the search window is the same
+    10 % of the frame and the evaluations-per-sample ratio equals the full-size workload's."""
+    from oracle_api import Checker, frame_cfg, ref_available
+    from sac_amd.synth import synth_pcm
+
+    kind = "reference" if ref_available() else "port"
+    chk = Checker("ref" if kind == "reference" else "orc")
+    n = int(seconds * RATE)
+    raw = synth_pcm(n, 2, seed=4242, rate=RATE)
+    cfg = frame_cfg("high", num_threads=nthreads, reset=1)
+    t = time.time()
+    r = chk.encode_frame(raw, cfg, n)
+    dt = time.time() - t
+    return {"value": raw.size / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": kind,
+            "seconds": dt, "bps": 8 * len(r["record"]) / raw.size,
+            "sample": f"1 stereo frame of {seconds:g} s 44.1 kHz/16-bit, --high --opt-cfg=dds,{nthreads} --opt-reset, "
+                      f"max frame length {seconds:g} s (search window 10 % of the frame as in the 20 s workload); "
+                      + ("genuine reference objects (oracle/_ref), candidates evaluated serially on 1 core"
+                         if kind == "reference" else "oracle restatement, 1 core")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 64)), help="frames per GPU per step")
+    ap.add_argument("--seconds", type=float, default=float(os.environ.get("SAC_BENCH_SECONDS", 20.0)), help="frame length")
+    ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
+    ap.add_argument("--mode", default="high")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="decode every record with the oracle afterwards (slow)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import sac_amd.api as api
+
+    frames, il, n = make_batch(args.frames, args.seconds, seed0=1000 + 1000 * rank)
+    d_pcm = torch.from_numpy(il).to(device)            # interleaved L/R int16, resident in HBM
+    torch.cuda.synchronize()
+    framesize = int(20 * RATE) if args.seconds >= 20 else n   # reference: max_framelen(20 s) * rate
+    ctx = api.Context(2, max(n, 16), args.frames, device=local_rank)
+    frame_off = np.arange(args.frames, dtype=np.int64) * n
+    nsamp = np.full(args.frames, n, np.int32)
+    cfg = api.make_cfg(args.mode, num_threads=args.dds_n, reset=1)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        ctx.attach_s16_device(d_pcm.data_ptr(), frame_off, nsamp, framesize)
+        ctx.analyse(cfg)
+        recs, prof = ctx.encode_frames(cfg)
+        if dist is not None:
+            allrecs = gather_records(recs, rank, world, device)
+        else:
+            allrecs = recs
+        return recs, allrecs
+
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs, allrecs = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kt = ctx.kernel_times(reset=True)
+
+    samples_per_step = args.frames * n * 2 * world
+    value = samples_per_step * args.steps / dt / 1e6
+    if rank == 0:
+        bps = 8 * sum(len(r) for r in allrecs) / samples_per_step
+        # ---- roofline of the dominant kernel family (HIP-event times on the context's stream)
+        dom = max(("ols", "lms", "bias", "coder", "cost"), key=lambda k: kt[k]["ms"])
+        E, frac = cfg.maxnfunc, cfg.fraction
+        nopt = min(n, int(np.ceil(framesize * frac)))
+        steps_per_frame_ch = E * nopt + n                       # predictor channel-steps
+        launches = max(kt[dom]["launches"], 1)
+        if dom in STAGE_BYTES:
+            alg_bytes = STAGE_BYTES[dom] * steps_per_frame_ch * 2 * args.frames * args.steps / launches
+        elif dom == "coder":
+            alg_bytes = (4 + bps / 8) * n * 2 * args.frames * args.steps / launches
+        else:
+            alg_bytes = 4 * E * nopt * 2 * args.frames * args.steps / launches
+        avg_s = kt[dom]["ms"] / 1e3 / launches
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        out = {
+            "metric": "encode MSamples/s + bps, 16-bit/44.1kHz stereo, --high; 1/2/4/8 MI355X",
+            "value": value, "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.frames} frames/GPU x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
+                                   f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
+                       "frames_per_gpu": args.frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
+                       "parallelism": f"frames sharded over {world} GPU(s), RCCL record gather"},
+            "bps": bps, "x_realtime": (args.frames * world * args.seconds * args.steps) / dt,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "latency/fp64-VALU-bound recurrences; HBM fraction is expected to be << 1 % (SURVEY.md 8d)"},
+            "kernel_ms": {k: round(v["ms"], 2) for k, v in kt.items()},
+            "kernel_launches": {k: v["launches"] for k, v in kt.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(nthreads=args.dds_n)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        if args.verify:
+            from oracle_api import Checker
+            orc = Checker("orc")
+            ok = all(np.array_equal(orc.decode_frame(r, 2, max(n, 16))[0], f) for r, f in zip(recs, frames))
+            out["verified_lossless"] = bool(ok)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

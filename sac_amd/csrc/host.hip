@@ -243,6 +243,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
 int run_costs(sacamd_ctx *c, int kind, const std::vector<long long> &off, const std::vector<int> &n, const int *d_err,
               std::vector<double> &out);
 
+int bitplane_costs(sacamd_ctx *c, const std::vector<long long> &off, const std::vector<int> &n, std::vector<double> &out);
+
 void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start, int *nopt) {
   const int n = c->nsamp[f];
   const int w = std::min(n, static_cast<int>(std::ceil(c->framesize * cfg->fraction)));   // libsac.cpp:367
@@ -439,8 +441,12 @@ API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const i
   std::vector<int> n(items.size());
   for (size_t i = 0; i < items.size(); i++) { off[i] = items[i].off_err; n[i] = items[i].n; }
   std::vector<double> cv;
-  if (cfg->optimize_cost == SACAMD_COST_BITPLANE) return fail(c, SACAMD_ERR_ARG, "bitplane search cost: use sacamd_encode_frames path");
-  r = run_costs(c, cfg->optimize_cost, off, n, c->d_err.p, cv);
+  if (cfg->optimize_cost == SACAMD_COST_BITPLANE) {
+    // CostBitplane (cost.h:144-176): S2U, maxbpn from the window, full coder, byte count
+    r = bitplane_costs(c, off, n, cv);
+  } else {
+    r = run_costs(c, cfg->optimize_cost, off, n, c->d_err.p, cv);
+  }
   if (r) return r;
   // GetCost: sum over file channels 0,1 (libsac.cpp:355-361)
   for (int i = 0; i < ncand; i++) {

@@ -9,6 +9,7 @@
 // context tables (32+8+16 entries of {cnt,val}) sit in LDS, one private slab per lane.
 #pragma once
 #include "canon.h"
+#include "libm_port.h"
 #include "params.h"
 
 namespace sacamd {
@@ -67,7 +68,7 @@ SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *
     const double var0 = fmax(0.0, rvar);
     const double diff = delta - rmean;
     const double z = diff * diff / (var0 + 1E-5);
-    const double w = exp(-0.5 * z);
+    const double w = sa_exp(-0.5 * z);
     const int cc[3] = {c0, c1, c2};
     for (int q = 0; q < 3; q++) {
       const int c = cc[q];

@@ -18,6 +18,7 @@
 // small dots of the serial chain use the canonical order (canon.h).
 #pragma once
 #include "canon.h"
+#include "libm_port.h"
 #include "params.h"
 
 namespace sacamd {
@@ -201,7 +202,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const double err2 = err * err;
           const double R = fmax(ch.S0 - ch.S1, 1e-5);
           const double nis = err2 / (phi + R);
-          const double mm = exp(-p.lm_alpha * nis);
+          const double mm = sa_exp(-p.lm_alpha * nis);
           const double alpha = fma(0.999 - 0.99, mm, 0.99);
           const double denom = 1. / (alpha + phi);
           const double inv_alpha = 1.0 / alpha;
@@ -237,7 +238,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
             zm[e] = 1.0 * ch.smrs[e];
           }
           const double maxz = fmax(zm[0], zm[1]);
-          const double w0 = exp(zm[0] - maxz), w1 = exp(zm[1] - maxz);
+          const double w0 = sa_exp(zm[0] - maxz), w1 = sa_exp(zm[1] - maxz);
           const double inv = 1.0 / (w0 + w1);
           ch.smw[0] = w0 * inv; ch.smw[1] = w1 * inv;
         }

@@ -16,6 +16,7 @@
 // fused/unfused pattern (canon.h) -- so p_lpc is bit-identical to the reference build.
 #pragma once
 #include "canon.h"
+#include "libm_port.h"
 #include "params.h"
 
 namespace sacamd {
@@ -96,7 +97,7 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
       val = (double)self[t];
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
-      const double c = pow(esum + p.beta_add, -p.beta_pow);
+      const double c = sa_pow(esum + p.beta_add, -p.beta_pow);
       ff = one_m_lambda * c;
     });
     ex.par([&](int l) { if (l == 0) p_out[t] = pred; });
