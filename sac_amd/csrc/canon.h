@@ -64,6 +64,39 @@ SA_HD double dot_canon(const double *x, const double *y, int n) {
   return total;
 }
 
+// dot_canon with a compile-time length (first operand may live in registers)
+template <int N, class A, class B>
+SA_HD double dot_canon_n(A a, B b) {
+  double total = 0.0;
+  constexpr int blocks = (N >= 8) ? N / 8 : 0;
+  if (blocks) {
+    double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < blocks * 8; i += 8) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) { s[c] = fma(a(i + c), b(i + c), s[c]); t[c] = fma(a(i + 4 + c), b(i + 4 + c), t[c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) s[c] = s[c] + t[c];
+    total = ((s[0] + s[1]) + s[2]) + s[3];
+  }
+  constexpr int i0 = blocks * 8;
+  double init = 0.0;
+  constexpr int rem = N - i0;
+  constexpr int g = (rem >= 4) ? 4 : 0;
+  if (g) {
+    const double v1 = fma(a(i0 + 1), b(i0 + 1), a(i0) * b(i0));
+    const double v2 = fma(a(i0 + 3), b(i0 + 3), a(i0 + 2) * b(i0 + 2));
+    init = init + (v1 + v2);
+  }
+  constexpr int j0 = i0 + g, m = N - j0;
+  int k = 0;
+  if (m >= 2) { init = init + a(j0) * b(j0); init = init + a(j0 + 1) * b(j0 + 1); k = 2; }
+  if (k < m) init = fma(a(j0 + k), b(j0 + k), init);
+  total += init;
+  return total;
+}
+
 SA_HD double sgnd(double x) { return (double)((x > 0) - (x < 0)); }
 SA_HD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 SA_HD int clampi32(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -25,7 +25,7 @@ constexpr int kLaplacePlanes = 18;
 constexpr int kCoderChunk = 64;
 constexpr int kCoderHalo = 32;
 
-struct CntL { unsigned short p1, cnt; };
+struct CntL { unsigned short p1, cnt; };     // LinearCounterLimit as one 32-bit word
 
 struct CoderModel {
   CntL csig1[80], cref0[32], cref1[256], cref2[64], cref3[160], p_laplace[32];
@@ -34,9 +34,11 @@ struct CoderModel {
   unsigned char sse_lb[160];
 };
 
-struct CoderDesc {           // per-sample descriptor of one chunk (structure of arrays in LDS)
-  unsigned short pest[kCoderChunk], i1[kCoderChunk], i2[kCoderChunk], i3[kCoderChunk], i4[kCoderChunk];
-  unsigned char type[kCoderChunk], bit[kCoderChunk], mix[kCoderChunk], s1[kCoderChunk], s2[kCoderChunk];
+// read-only tables staged in LDS
+struct CoderTabs {
+  short fwd[kPScale];          // LogDomain::Fwd
+  unsigned pinv[4097];         // x in [-2048,2048] -> p = clamp(Inv(x)) | Fwd(p) << 16
+  unsigned short divt[304];    // PSCALE / (cnt + 3)   (counter.h:40-51)
 };
 
 struct CoderWin {            // staged data window of one chunk (with halo)
@@ -44,14 +46,21 @@ struct CoderWin {            // staged data window of one chunk (with halo)
   unsigned char msb[kCoderChunk + 2 * kCoderHalo];
 };
 
+// per-sample descriptor, packed into four ints held by the lane that computed it
+struct CoderDescR {
+  int a;   // pest | i1 << 16
+  int b;   // i2 | i3 << 16
+  int c;   // i4 | mix << 16 | s1 << 24
+  int d;   // s2 | type << 8 | bit << 9 | fwd(pest) << 16
+};
+
 struct RangeEnc {            // RangeCoderSH, encode side
   unsigned range, FFNum, Cache;
   unsigned long long lowc;
   unsigned char *out;
   int pos, cap;
-  bool store;                // only the lane that owns the output stores
-  SA_HD void init(unsigned char *o, int capacity, bool st) { range = 0xFFFFFFFFu; FFNum = 0; Cache = 0; lowc = 0; out = o; pos = 0; cap = capacity; store = st; }
-  SA_HD void put(unsigned b) { if (store && pos < cap) out[pos] = (unsigned char)b; pos++; }
+  SA_HD void init(unsigned char *o, int capacity) { range = 0xFFFFFFFFu; FFNum = 0; Cache = 0; lowc = 0; out = o; pos = 0; cap = capacity; }
+  SA_HD void put(unsigned b) { if (pos < cap) out[pos] = (unsigned char)b; pos++; }
   SA_HD void shift_low() {
     const unsigned Carry = (unsigned)(lowc >> 32), low = (unsigned)lowc;
     if (low < 0xFF000000u || Carry) {
@@ -74,30 +83,34 @@ SA_HD int idiv_s64(long long val, int s) { return (int)(val < 0 ? -(((-val) + (1
 SA_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 SA_HD int ilog2i(int v) { int nb = 0; while (v >>= 1) nb++; return nb; }
 
-SA_HD void cntl_update(CntL &c, int bit, int limit) {           // counter.h:58-68
+// LinearCounterLimit::update (counter.h:58-68) on a loaded value; returns the new packed word
+SA_HD CntL cntl_next(CntL c, int bit, int limit, const unsigned short *divt) {
   unsigned cnt = c.cnt;
   if ((int)cnt < limit) cnt++;
-  const int d = kPScale / ((int)cnt + 3);
+  const int d = divt[cnt];
   const int p1 = c.p1;
   const int dp = bit ? ((kPScale - p1) * d) >> kPBits : -((p1 * d) >> kPBits);
-  c.p1 = (unsigned short)clampi(p1 + dp, 1, kPScaleM);
-  c.cnt = (unsigned short)cnt;
+  CntL r; r.p1 = (unsigned short)clampi(p1 + dp, 1, kPScaleM); r.cnt = (unsigned short)cnt;
+  return r;
 }
-SA_HD void cnt16_update(unsigned short &p1, int bit, int L) {   // counter.h:31-37
-  const int err = (bit << kPBits) - (int)p1;
-  p1 = (unsigned short)clampi((int)p1 + idiv_s(L * err, kPBits), 1, kPScaleM);
+SA_HD unsigned short cnt16_next(int p1, int bit, int L) {       // LinearCounter16::update(bit,L), counter.h:31-37
+  const int err = (bit << kPBits) - p1;
+  return (unsigned short)clampi(p1 + idiv_s(L * err, kPBits), 1, kPScaleM);
 }
-SA_HD int squash(const unsigned short *inv, int x) { return x < -2047 ? 1 : (x > 2047 ? kPScaleM : (int)inv[x + 2047]); }
+SA_HD void cnt16_update(unsigned short &p1, int bit, int L) { p1 = cnt16_next(p1, bit, L); }
+// squash+stretch: x -> packed (p | Fwd(p) << 16)
+SA_HD unsigned pinv_lookup(const unsigned *pinv, int x) { return pinv[clampi(x, -2048, 2048) + 2048]; }
+SA_HD int squash(const unsigned *pinv, int x) { return (int)(pinv_lookup(pinv, x) & 0xffff); }
 
 template <int N>
-SA_HD int mix_predict(const int *w, const int *st, const unsigned short *inv) {   // mixer.h:76-87
+SA_HD int mix_dot(const int *w, const int *st) {                 // mixer.h:76-85 (returns the stretched-domain sum)
   long long sum = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) sum += (long long)(w[i] * st[i]);
-  return clampi(squash(inv, idiv_s64(sum, 16)), 1, kPScaleM);
+  return idiv_s64(sum, 16);
 }
 template <int N>
-SA_HD void mix_update(int *w, const int *st, int pd, int bit, int rate) {          // mixer.h:88-96
+SA_HD void mix_next(int *w, const int *st, int pd, int bit, int rate) {   // mixer.h:88-96, in place on loaded weights
   const int err = (bit << kPBits) - pd;
 #pragma unroll
   for (int i = 0; i < N; i++) {
@@ -106,19 +119,29 @@ SA_HD void mix_update(int *w, const int *st, int pd, int bit, int rate) {       
     w[i] = clampi(w[i] + wd, -(1 << 19), (1 << 19) - 1);
   }
 }
-// SSENL<N>::Predict (sse.h:101-113); returns prediction, *pq = quantised bin
-template <int N>
-SA_HD int sse_predict(const unsigned short *map /*[N+1]*/, int stp, int *pq) {
+// SSENL<N>::Predict (sse.h:101-113) split: bin index / interpolation
+template <int N> SA_HD void sse_bin(int stp, int *pq, int *pmod) {
   constexpr int tscale = 2662, xscale = (2 * tscale) / (N - 1);
   int q = stp + tscale;
   q = q < 0 ? 0 : (q > 2 * tscale ? 2 * tscale : q);
-  const int pquant = q / xscale, pmod = q - pquant * xscale;
-  const int pl = map[pquant], ph = map[pquant + 1];
-  *pq = pquant;
+  *pq = q / xscale; *pmod = q - (*pq) * xscale;
+}
+template <int N> SA_HD int sse_interp(int pl, int ph, int pmod) {
+  constexpr int xscale = (2 * 2662) / (N - 1);
   return clampi((pl * (xscale - pmod) + ph * pmod) / xscale, 1, kPScaleM);
 }
 
-SA_HD void coder_model_init(CoderModel &m, const unsigned short *inv, const unsigned short *plap_init, int lane, int nl) {
+SA_HD void coder_tabs_init(CoderTabs &T, const short *g_fwd, const unsigned short *g_inv, int lane, int nl) {
+  for (int i = lane; i < kPScale; i += nl) T.fwd[i] = g_fwd[i];
+  for (int i = lane; i < 4097; i += nl) {
+    const int x = i - 2048;
+    const int p = x < -2047 ? 1 : (x > 2047 ? kPScaleM : clampi((int)g_inv[x + 2047], 1, kPScaleM));
+    T.pinv[i] = (unsigned)p | ((unsigned)(unsigned short)g_fwd[p] << 16);
+  }
+  for (int i = lane; i < 304; i += nl) T.divt[i] = (unsigned short)(kPScale / (i + 3));
+}
+
+SA_HD void coder_model_init(CoderModel &m, const CoderTabs &T, const unsigned short *plap_init, int lane, int nl) {
   auto fill = [&](CntL *a, int n) { for (int i = lane; i < n; i += nl) { a[i].p1 = kPScale >> 1; a[i].cnt = 0; } };
   fill(m.csig1, 80); fill(m.cref0, 32); fill(m.cref1, 256); fill(m.cref2, 64); fill(m.cref3, 160);
   for (int i = lane; i < 32; i += nl) { m.p_laplace[i].p1 = plap_init[i]; m.p_laplace[i].cnt = 0; }
@@ -127,8 +150,7 @@ SA_HD void coder_model_init(CoderModel &m, const unsigned short *inv, const unsi
   if (lane < 2) m.ssemix[lane] = 0;
   for (int i = lane; i < 160 * 2 * 16; i += nl) {
     const int k = i & 15;
-    const int x = k * 380 - 2662;       // SSENL<15>: xscale 380, tscale 2662 (sse.h:91-99)
-    (&m.sse[0][0][0])[i] = (unsigned short)squash(inv, x);
+    (&m.sse[0][0][0])[i] = (unsigned short)squash(T.pinv, k * 380 - 2662);   // SSENL<15>: xscale 380, tscale 2662 (sse.h:91-99)
   }
   for (int i = lane; i < 160; i += nl) m.sse_lb[i] = 0;
 }
@@ -140,7 +162,7 @@ SA_HD int msb_seen(const CoderWin &W, int li, bool before, int bpn) {
   return before ? (m >= bpn ? m : 0) : (m > bpn ? m : 0);
 }
 
-SA_HD void coder_describe(const CoderWin &W, CoderDesc &D, int i, int s, int n, int bpn, const unsigned short *laplace) {
+SA_HD CoderDescR coder_describe(const CoderWin &W, const CoderTabs &T, int i, int s, int n, int bpn, const unsigned short *laplace) {
   const int li = i + kCoderHalo;
   // GetAvgSum(32), vle.cpp:54-68
   unsigned long long nsum = 0; int nidx = 0;
@@ -159,14 +181,14 @@ SA_HD void coder_describe(const CoderWin &W, CoderDesc &D, int i, int s, int n, 
     sig[2 * d] = (s < n - d) ? msb_seen(W, li + d, false, bpn) : 0;
   }
   const int val = W.val[li];
-  D.pest[i] = (unsigned short)pest;
-  D.bit[i] = (unsigned char)((val >> bpn) & 1);
-  D.type[i] = sig[0] ? 1 : 0;    // 1 = refinement
-  D.s1[i] = (unsigned char)(((pest >> 11) << 1) + (sig[0] ? 1 : 0));
-  D.s2[i] = (unsigned char)(32 + (sig[0] ? 1 : 0) + ((sig[1] ? 1 : 0) << 1) + ((sig[2] ? 1 : 0) << 2) + ((sig[3] ? 1 : 0) << 3) +
-                            ((sig[4] ? 1 : 0) << 4) + ((sig[5] ? 1 : 0) << 5) + ((sig[6] ? 1 : 0) << 6));
+  const int bit = (val >> bpn) & 1;
+  const int s1 = ((pest >> 11) << 1) + (sig[0] ? 1 : 0);
+  const int s2 = 32 + (sig[0] ? 1 : 0) + ((sig[1] ? 1 : 0) << 1) + ((sig[2] ? 1 : 0) << 2) + ((sig[3] ? 1 : 0) << 3) +
+                 ((sig[4] ? 1 : 0) << 4) + ((sig[5] ? 1 : 0) << 5) + ((sig[6] ? 1 : 0) << 6);
+  int i1, i2, i3 = 0, i4 = 0, mix, type;
   if (sig[0]) {
     // PredictRef, vle.cpp:81-130
+    type = 1;
     const int lval = s > 0 ? W.val[li - 1] : 0, lval2 = s > 1 ? W.val[li - 2] : 0;
     const int nval = s < n - 1 ? W.val[li + 1] : 0, nval2 = s < n - 2 ? W.val[li + 2] : 0;
     const int b0 = val >> (bpn + 1), b1 = lval >> bpn, b2 = nval >> (bpn + 1), b3 = lval2 >> bpn, b4 = nval2 >> (bpn + 1);
@@ -175,12 +197,13 @@ SA_HD void coder_describe(const CoderWin &W, CoderDesc &D, int i, int s, int n, 
     const int xm = (x0 + x1 + x2 + x3 + x4) / 5;
     const int d0 = x0 > xm, d1 = x1 > xm;
     const int ctx1 = (b0 & 15) + ((b1 & 15) << 4) + ((b2 & 15) << 8);
-    const int ctx2 = (c0 + (c1 << 1) + (c2 << 2) + (c3 << 3)) + (d0 << 4) + (d1 << 5);
-    const int ctx3 = sig[1] + sig[2] + sig[3] + sig[4] + sig[5] + sig[6] + sig[7] + sig[8];
-    D.i1[i] = (unsigned short)sig[0]; D.i2[i] = (unsigned short)(ctx1 & 255); D.i3[i] = (unsigned short)ctx2; D.i4[i] = (unsigned short)ctx3;
-    D.mix[i] = (unsigned char)(((((pest >> 12) << 1) + d0) << 1) + (b0 & 1));
+    i1 = sig[0]; i2 = ctx1 & 255;
+    i3 = (c0 + (c1 << 1) + (c2 << 2) + (c3 << 3)) + (d0 << 4) + (d1 << 5);
+    i4 = sig[1] + sig[2] + sig[3] + sig[4] + sig[5] + sig[6] + sig[7] + sig[8];
+    mix = ((((pest >> 12) << 1) + d0) << 1) + (b0 & 1);
   } else {
     // PredictSig + CountSig, vle.cpp:144-177
+    type = 0;
     int ctx1 = 0;
     for (int q = 0; q < 16; q++) if (sig[q + 1]) ctx1 += 1 << q;
     int n1 = 0, n2 = 0;
@@ -191,64 +214,80 @@ SA_HD void coder_describe(const CoderWin &W, CoderDesc &D, int i, int s, int n, 
     // state&15: the previous four samples of this plane, 1 = coded on the significance path
     int st = 0;
     for (int d = 1; d <= 4; d++) if (s - d >= 0 && !(W.msb[li - d] > bpn)) st |= 1 << (d - 1);
-    D.i1[i] = (unsigned short)ctx1; D.i2[i] = (unsigned short)n2; D.i3[i] = 0; D.i4[i] = 0;
-    D.mix[i] = (unsigned char)((st << 3) + ((n1 >= 3 ? 3 : n1) << 1) + (n2 > 0 ? 1 : 0));
+    i1 = ctx1; i2 = n2;
+    mix = (st << 3) + ((n1 >= 3 ? 3 : n1) << 1) + (n2 > 0 ? 1 : 0);
   }
+  CoderDescR D;
+  D.a = pest | (i1 << 16);
+  D.b = i2 | (i3 << 16);
+  D.c = i4 | (mix << 16) | (s1 << 24);
+  D.d = s2 | (type << 8) | (bit << 9) | ((int)(unsigned short)T.fwd[pest] << 16);
+  return D;
 }
 
-// ---- the adaptive chain for one decision (uniform across the wave)
-SA_HD void coder_step(CoderModel &M, CntL *csig0, const short *fwd, const unsigned short *inv, const CoderDesc &D, int i,
-                      int bpn, RangeEnc &rc, bool writer) {
-  const int bit = D.bit[i], pest = D.pest[i];
-  CntL &pl = M.p_laplace[bpn];
-  int p1;            // mixer output
-  int st[5];
-  if (D.type[i]) {
-    CntL &c1 = M.cref0[D.i1[i]], &c2 = M.cref1[D.i2[i]], &c3 = M.cref2[D.i3[i]], &c4 = M.cref3[D.i4[i]];
-    int *w = M.lmixref[D.mix[i]];
-    st[0] = fwd[pest]; st[1] = fwd[pl.p1]; st[2] = fwd[c1.p1]; st[3] = fwd[c2.p1]; st[4] = fwd[c3.p1];
-    p1 = mix_predict<5>(w, st, inv);
-    // SSE + final mix
-    const int sp1 = fwd[p1];
-    int q1, q2;
-    unsigned short *m1 = M.sse[D.s1[i]][M.sse_lb[D.s1[i]]], *m2 = M.sse[D.s2[i]][M.sse_lb[D.s2[i]]];
-    const int pr1 = sse_predict<15>(m1, sp1, &q1);
-    const int pr2 = sse_predict<15>(m2, fwd[pr1], &q2);
-    int sf[2] = {fwd[(pr1 + pr2 + 1) >> 1], sp1};
-    const int p = mix_predict<2>(M.ssemix, sf, inv);
-    rc.encode((unsigned)p, bit);
-    if (writer) {
-      cntl_update(pl, bit, 150); cntl_update(c1, bit, 150); cntl_update(c2, bit, 150); cntl_update(c3, bit, 150); cntl_update(c4, bit, 150);
-      mix_update<5>(w, st, p1, bit, 800);
-      cnt16_update(m1[q1], bit, 250); cnt16_update(m1[q1 + 1], bit, 250); M.sse_lb[D.s1[i]] = (unsigned char)bit;
-      // note: when s1 == s2 cannot happen (s1 < 32 <= s2)
-      unsigned short *m2b = M.sse[D.s2[i]][0] + 0;   // re-derive after lb of s1 changed (distinct ctx, so unaffected)
-      (void)m2b;
-      cnt16_update(m2[q2], bit, 250); cnt16_update(m2[q2 + 1], bit, 250); M.sse_lb[D.s2[i]] = (unsigned char)bit;
-      mix_update<2>(M.ssemix, sf, p, bit, 250);
-    }
+// ---- the adaptive chain for one decision.  c1sig: the (possibly prefetched) csig0 entry for a
+// significance decision; returns its updated value through *c1out.
+SA_HD void coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, CntL c1sig, CntL *c1out, RangeEnc &rc) {
+  const int pest = D.a & 0xffff, i1 = (D.a >> 16) & 0xffff, i2 = D.b & 0xffff, i3 = (D.b >> 16) & 0xffff;
+  const int i4 = D.c & 0xffff, mixc = (D.c >> 16) & 0xff, s1 = (D.c >> 24) & 0xff, s2 = D.d & 0xff;
+  const int type = (D.d >> 8) & 1, bit = (D.d >> 9) & 1, st_pest = (short)(D.d >> 16);
+  (void)pest;
+  // ---- round 1: every state word this decision touches
+  const CntL pl = M.p_laplace[bpn];
+  const int lb1 = M.sse_lb[s1], lb2 = M.sse_lb[s2];
+  int sw[2] = {M.ssemix[0], M.ssemix[1]};
+  unsigned short *m1 = M.sse[s1][lb1], *m2 = M.sse[s2][lb2];
+  int st[5], w[5];
+  CntL c1, c2, c3 = pl, c4 = pl;
+  int x;
+  if (type) {
+    c1 = M.cref0[i1]; c2 = M.cref1[i2]; c3 = M.cref2[i3]; c4 = M.cref3[i4];
+    const int *wp = M.lmixref[mixc];
+#pragma unroll
+    for (int q = 0; q < 5; q++) w[q] = wp[q];
+    st[0] = st_pest; st[1] = T.fwd[pl.p1]; st[2] = T.fwd[c1.p1]; st[3] = T.fwd[c2.p1]; st[4] = T.fwd[c3.p1];
+    x = mix_dot<5>(w, st);
   } else {
-    CntL &c1 = csig0[D.i1[i]];
-    CntL &c2 = M.csig1[D.i2[i]];
-    int *w = M.lmixsig[D.mix[i]];
-    st[0] = fwd[pl.p1]; st[1] = fwd[c1.p1]; st[2] = fwd[c2.p1];
-    p1 = mix_predict<3>(w, st, inv);
-    const int sp1 = fwd[p1];
-    int q1, q2;
-    unsigned short *m1 = M.sse[D.s1[i]][M.sse_lb[D.s1[i]]], *m2 = M.sse[D.s2[i]][M.sse_lb[D.s2[i]]];
-    const int pr1 = sse_predict<15>(m1, sp1, &q1);
-    const int pr2 = sse_predict<15>(m2, fwd[pr1], &q2);
-    int sf[2] = {fwd[(pr1 + pr2 + 1) >> 1], sp1};
-    const int p = mix_predict<2>(M.ssemix, sf, inv);
-    rc.encode((unsigned)p, bit);
-    if (writer) {
-      cntl_update(pl, bit, 150); cntl_update(c1, bit, 300); cntl_update(c2, bit, 300);
-      mix_update<3>(w, st, p1, bit, 700);
-      cnt16_update(m1[q1], bit, 250); cnt16_update(m1[q1 + 1], bit, 250); M.sse_lb[D.s1[i]] = (unsigned char)bit;
-      cnt16_update(m2[q2], bit, 250); cnt16_update(m2[q2 + 1], bit, 250); M.sse_lb[D.s2[i]] = (unsigned char)bit;
-      mix_update<2>(M.ssemix, sf, p, bit, 250);
-    }
+    c1 = c1sig; c2 = M.csig1[i2];
+    const int *wp = M.lmixsig[mixc];
+#pragma unroll
+    for (int q = 0; q < 3; q++) w[q] = wp[q];
+    st[0] = T.fwd[pl.p1]; st[1] = T.fwd[c1.p1]; st[2] = T.fwd[c2.p1]; st[3] = 0; st[4] = 0;
+    x = mix_dot<3>(w, st);
   }
+  const unsigned pk = pinv_lookup(T.pinv, x);
+  const int p1 = (int)(pk & 0xffff), sp1 = (short)(pk >> 16);
+  int q1, r1, q2, r2;
+  sse_bin<15>(sp1, &q1, &r1);
+  const int m1a = m1[q1], m1b = m1[q1 + 1];
+  const int pr1 = sse_interp<15>(m1a, m1b, r1);
+  sse_bin<15>(T.fwd[pr1], &q2, &r2);
+  const int m2a = m2[q2], m2b = m2[q2 + 1];
+  const int pr2 = sse_interp<15>(m2a, m2b, r2);
+  int sf[2] = {T.fwd[(pr1 + pr2 + 1) >> 1], sp1};
+  const int p = (int)(pinv_lookup(T.pinv, mix_dot<2>(sw, sf)) & 0xffff);
+  rc.encode((unsigned)p, bit);
+  // ---- updates (computed from the loaded values; stores only)
+  M.p_laplace[bpn] = cntl_next(pl, bit, 150, T.divt);
+  if (type) {
+    M.cref0[i1] = cntl_next(c1, bit, 150, T.divt); M.cref1[i2] = cntl_next(c2, bit, 150, T.divt);
+    M.cref2[i3] = cntl_next(c3, bit, 150, T.divt); M.cref3[i4] = cntl_next(c4, bit, 150, T.divt);
+    mix_next<5>(w, st, p1, bit, 800);
+    int *wp = M.lmixref[mixc];
+#pragma unroll
+    for (int q = 0; q < 5; q++) wp[q] = w[q];
+  } else {
+    *c1out = cntl_next(c1, bit, 300, T.divt);
+    M.csig1[i2] = cntl_next(c2, bit, 300, T.divt);
+    mix_next<3>(w, st, p1, bit, 700);
+    int *wp = M.lmixsig[mixc];
+#pragma unroll
+    for (int q = 0; q < 3; q++) wp[q] = w[q];
+  }
+  m1[q1] = cnt16_next(m1a, bit, 250); m1[q1 + 1] = cnt16_next(m1b, bit, 250); M.sse_lb[s1] = (unsigned char)bit;
+  m2[q2] = cnt16_next(m2a, bit, 250); m2[q2 + 1] = cnt16_next(m2b, bit, 250); M.sse_lb[s2] = (unsigned char)bit;
+  mix_next<2>(sw, sf, p, bit, 250);
+  M.ssemix[0] = sw[0]; M.ssemix[1] = sw[1];
 }
 
 // ---- MapEncoder (map.cpp:3-101): 2 x 32768 used-flags, serial
@@ -258,14 +297,14 @@ struct MapModel {
   unsigned short sse[2][33];
   int lb;
 };
-SA_HD void map_model_init(MapModel &m, const unsigned short *inv) {
+SA_HD void map_model_init(MapModel &m, const unsigned *pinv) {
   for (int i = 0; i < 24; i++) m.cnt[i] = kPScale >> 1;
   for (int i = 0; i < 256; i++) m.cctx[i] = kPScale >> 1;
   for (int a = 0; a < 4; a++) for (int b = 0; b < 5; b++) { m.mixl[a][b] = 0; m.mixh[a][b] = 0; }
   m.finalmix[0] = m.finalmix[1] = 0; m.lb = 0;
-  for (int i = 0; i <= 32; i++) { const int x = squash(inv, i * 171 - 2662); m.sse[0][i] = (unsigned short)x; m.sse[1][i] = (unsigned short)x; }   // SSENL<32>: xscale 171
+  for (int i = 0; i <= 32; i++) { const int x = squash(pinv, i * 171 - 2662); m.sse[0][i] = (unsigned short)x; m.sse[1][i] = (unsigned short)x; }   // SSENL<32>: xscale 171
 }
-SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char *uh, const short *fwd, const unsigned short *inv, RangeEnc &rc, bool writer) {
+SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char *uh, const short *fwd, const unsigned *pinv, RangeEnc &rc) {
   for (int i = 1; i <= 1 << 15; i++) {
     for (int hi = 0; hi < 2; hi++) {
       const unsigned char *a = hi ? uh : ul;
@@ -281,21 +320,20 @@ SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char 
       unsigned short *px = &m.cctx[(hi ? 32 : 0) + sctx];
       int *w = hi ? m.mixh[ctx1 + (ctx3 << 1)] : m.mixl[ctx1 + (ctx3 << 1)];
       int st[5] = {fwd[*pc1], fwd[*pc2], fwd[*pc3], fwd[*pc4], fwd[*px]};
-      const int p1 = mix_predict<5>(w, st, inv);
-      int q;
-      const int sp1 = fwd[p1];
+      const unsigned pk = pinv_lookup(pinv, mix_dot<5>(w, st));
+      const int p1 = (int)(pk & 0xffff), sp1 = (short)(pk >> 16);
+      int q, r;
       unsigned short *mp = m.sse[m.lb];
-      const int ps = sse_predict<32>(mp, sp1, &q);
+      sse_bin<32>(sp1, &q, &r);
+      const int ps = sse_interp<32>(mp[q], mp[q + 1], r);
       int sf[2] = {fwd[ps], sp1};
-      const int p = mix_predict<2>(m.finalmix, sf, inv);
+      const int p = (int)(pinv_lookup(pinv, mix_dot<2>(m.finalmix, sf)) & 0xffff);
       const int bit = a[i];
       rc.encode((unsigned)p, bit);
-      if (writer) {
-        cnt16_update(*pc1, bit, 500); cnt16_update(*pc2, bit, 500); cnt16_update(*pc3, bit, 500); cnt16_update(*pc4, bit, 500); cnt16_update(*px, bit, 500);
-        mix_update<5>(w, st, p1, bit, 1000);
-        cnt16_update(mp[q], bit, 300); cnt16_update(mp[q + 1], bit, 300); m.lb = bit;
-        mix_update<2>(m.finalmix, sf, p, bit, 500);
-      }
+      cnt16_update(*pc1, bit, 500); cnt16_update(*pc2, bit, 500); cnt16_update(*pc3, bit, 500); cnt16_update(*pc4, bit, 500); cnt16_update(*px, bit, 500);
+      mix_next<5>(w, st, p1, bit, 1000);
+      cnt16_update(mp[q], bit, 300); cnt16_update(mp[q + 1], bit, 300); m.lb = bit;
+      mix_next<2>(m.finalmix, sf, p, bit, 500);
     }
   }
 }
@@ -304,30 +342,28 @@ SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char 
 template <class E>
 SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned char *used /*nullable: usedl, usedh*/,
                        const unsigned short *laplace, const short *g_fwd, const unsigned short *g_inv, const unsigned short *plap_init,
-                       CntL *csig0, unsigned char *out, int cap,
-                       CoderModel &M, CoderDesc &D, CoderWin &W, MapModel &MM, short *fwd, unsigned short *inv) {
-  // tables -> LDS, model init
+                       CntL *csig0, unsigned char *out, int cap, CoderModel &M, CoderTabs &T, CoderWin &W, MapModel &MM) {
   ex.par([&](int l) {
-    for (int i = l; i < kPScale; i += E::nl) fwd[i] = g_fwd[i];
-    for (int i = l; i < 4095; i += E::nl) inv[i] = g_inv[i];
+    coder_tabs_init(T, g_fwd, g_inv, l, E::nl);
     for (int i = l; i < 65536; i += E::nl) { csig0[i].p1 = kPScale >> 1; csig0[i].cnt = 0; }
   });
   ex.sync();
-  ex.par([&](int l) { coder_model_init(M, inv, plap_init, l, E::nl); });
+  ex.par([&](int l) { coder_model_init(M, T, plap_init, l, E::nl); });
   ex.sync();
-  // The adaptive chain is strictly serial: lane 0 runs it (single-lane LDS writes, no bank
-  // conflicts), the other lanes only take part in the parallel context computation.
+  // The adaptive chain is strictly serial: lane 0 runs it (single-lane LDS traffic), the other
+  // lanes take part in the parallel context computation and keep their sample's descriptor in
+  // registers, from where lane 0 fetches it with v_readlane.
   RangeEnc rc;
-  rc.init(out, cap, true);
+  rc.init(out, cap);
   if (used) {
     ex.par([&](int l) {
-      if (l == 0) { map_model_init(MM, inv); map_encode(MM, used, used + 32769, fwd, inv, rc, true); }
+      if (l == 0) { map_model_init(MM, T.pinv); map_encode(MM, used, used + 32769, T.fwd, T.pinv, rc); }
     });
     ex.sync();
   }
+  typename E::template Reg<int> da, db, dc, dd;
   for (int bpn = maxbpn; bpn >= 0; bpn--) {
     for (int s0 = 0; s0 < n; s0 += kCoderChunk) {
-      // stage window [s0-32, s0+64+32)
       ex.par([&](int l) {
         for (int q = l; q < kCoderChunk + 2 * kCoderHalo; q += E::nl) {
           const int k = s0 - kCoderHalo + q;
@@ -337,18 +373,41 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
         }
       });
       ex.sync();
-      ex.par([&](int l) { if (s0 + l < n) coder_describe(W, D, l, s0 + l, n, bpn, laplace); });
-      ex.sync();
-      const int cnt = (n - s0 < kCoderChunk) ? n - s0 : kCoderChunk;
       ex.par([&](int l) {
-        if (l == 0)
-          for (int i = 0; i < cnt; i++) coder_step(M, csig0, fwd, inv, D, i, bpn, rc, true);
+        CoderDescR D{0, 0, 0, 0};
+        if (s0 + l < n) D = coder_describe(W, T, l, s0 + l, n, bpn, laplace);
+        da[l] = D.a; db[l] = D.b; dc[l] = D.c; dd[l] = D.d;
+      });
+      const int cnt = (n - s0 < kCoderChunk) ? n - s0 : kCoderChunk;
+      // serial chain; the csig0 word of the NEXT significance decision is fetched one decision
+      // ahead (HBM/L2 latency) and forwarded from the register when both hit the same context
+      ex.lane0([&]() {
+        CoderDescR D{ex.lane_geti(da, 0), ex.lane_geti(db, 0), ex.lane_geti(dc, 0), ex.lane_geti(dd, 0)};
+        int idx = (D.a >> 16) & 0xffff;
+        CntL cur = csig0[((D.d >> 8) & 1) ? 0 : idx];
+        for (int i = 0; i < cnt; i++) {
+          CoderDescR Dn = D; CntL nxt = cur; int idxn = idx;
+          const bool has_next = i + 1 < cnt;
+          if (has_next) {
+            Dn = CoderDescR{ex.lane_geti(da, i + 1), ex.lane_geti(db, i + 1), ex.lane_geti(dc, i + 1), ex.lane_geti(dd, i + 1)};
+            idxn = (Dn.a >> 16) & 0xffff;
+            if (!((Dn.d >> 8) & 1)) nxt = csig0[idxn];
+          }
+          const bool is_sig = !((D.d >> 8) & 1);
+          CntL upd = cur;
+          coder_step(M, T, D, bpn, cur, &upd, rc);
+          if (is_sig) {
+            csig0[idx] = upd;
+            if (has_next && !((Dn.d >> 8) & 1) && idxn == idx) nxt = upd;
+          }
+          D = Dn; cur = nxt; idx = idxn;
+        }
       });
       ex.sync();
     }
   }
   int len = 0;
-  ex.par([&](int l) { if (l == 0) { rc.stop(); len = rc.pos; } });
+  ex.lane0([&]() { rc.stop(); len = rc.pos; });
   return len;   // valid on lane 0
 }
 

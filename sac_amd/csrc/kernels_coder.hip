@@ -6,11 +6,9 @@
 namespace sacamd {
 
 struct CoderLdsLayout {
-  static constexpr size_t o_fwd = 0;
-  static constexpr size_t o_inv = o_fwd + sizeof(short) * kPScale;
-  static constexpr size_t o_model = o_inv + sizeof(unsigned short) * 4096;
-  static constexpr size_t o_desc = (o_model + sizeof(CoderModel) + 15) / 16 * 16;
-  static constexpr size_t o_win = (o_desc + sizeof(CoderDesc) + 15) / 16 * 16;
+  static constexpr size_t o_tabs = 0;
+  static constexpr size_t o_model = (o_tabs + sizeof(CoderTabs) + 15) / 16 * 16;
+  static constexpr size_t o_win = (o_model + sizeof(CoderModel) + 15) / 16 * 16;
   static constexpr size_t o_map = (o_win + sizeof(CoderWin) + 15) / 16 * 16;
   static constexpr size_t total = (o_map + sizeof(MapModel) + 15) / 16 * 16;
 };
@@ -22,17 +20,15 @@ __global__ __launch_bounds__(64) void k_coder(const CoderJob *jobs, const int *s
                                                unsigned char *out, int *len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const CoderJob job = jobs[blockIdx.x];
-  short *fwd = reinterpret_cast<short *>(smem + CoderLdsLayout::o_fwd);
-  unsigned short *inv = reinterpret_cast<unsigned short *>(smem + CoderLdsLayout::o_inv);
+  CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
   CoderModel &M = *reinterpret_cast<CoderModel *>(smem + CoderLdsLayout::o_model);
-  CoderDesc &D = *reinterpret_cast<CoderDesc *>(smem + CoderLdsLayout::o_desc);
   CoderWin &W = *reinterpret_cast<CoderWin *>(smem + CoderLdsLayout::o_win);
   MapModel &MM = *reinterpret_cast<MapModel *>(smem + CoderLdsLayout::o_map);
   CntL *csig0 = reinterpret_cast<CntL *>(state + (size_t)blockIdx.x * stride);
   const unsigned short *plap = laplace + (size_t)kLaplacePlanes * kLaplaceAvg;
   ExecDev<64> ex;
   const int l = coder_stream(ex, s2u + job.off_in, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace, gfwd, ginv,
-                             plap, csig0, out + job.off_out, job.cap, M, D, W, MM, fwd, inv);
+                             plap, csig0, out + job.off_out, job.cap, M, T, W, MM);
   if (threadIdx.x == 0) len[blockIdx.x] = l;
 }
 

@@ -51,15 +51,18 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  ols_stage(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
+  if constexpr (NL == 64) ols_stage_fast(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
+  else ols_stage(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
 }
 
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p) {
   if (count <= 0) return;
   if (ols_class == 0) {
-    hipLaunchKernelGGL((k_ols<64, 32>), dim3(count), dim3(64), OlsLds::bytes(32), s, d_items, d_idx, v, d_p);
+    hipLaunchKernelGGL((k_ols<64, 32>), dim3(count), dim3(64), OlsLdsFast::bytes(32), s, d_items, d_idx, v, d_p);
   } else if (ols_class == 1) {
-    hipLaunchKernelGGL((k_ols<64, 64>), dim3(count), dim3(64), OlsLds::bytes(64), s, d_items, d_idx, v, d_p);
+    static bool once64 = false;
+    if (!once64) { hipFuncSetAttribute((const void *)k_ols<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OlsLdsFast::bytes(64)); once64 = true; }
+    hipLaunchKernelGGL((k_ols<64, 64>), dim3(count), dim3(64), OlsLdsFast::bytes(64), s, d_items, d_idx, v, d_p);
   } else {
     static bool once = false;
     if (!once) { hipFuncSetAttribute((const void *)k_ols<128, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OlsLds::bytes(96)); once = true; }

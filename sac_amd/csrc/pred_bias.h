@@ -15,15 +15,15 @@
 namespace sacamd {
 
 constexpr int kBiasCtx = 56;                       // 32 (ctx0) + 8 (ctx1) + 16 (ctx2)
-constexpr int kBiasSlabDoubles = 2 * kBiasCtx;     // {cnt,val} pairs
+constexpr int kBiasSlabDoubles = 2 * kBiasCtx + 12;   // {cnt,val} pairs + 4x3 SSLMS mixer weights
 
 // tables: this lane's slab of kBiasSlabDoubles doubles.  err/pred may be null.
 SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *psum, int mean,
                       int *err, int *pred, double *tables) {
   double *cnt = tables, *val = tables + kBiasCtx;
   for (int i = 0; i < kBiasCtx; i++) { cnt[i] = 4.0; val[i] = 0.0; }
-  double mixw[4][3];
-  for (int a = 0; a < 4; a++) for (int b = 0; b < 3; b++) mixw[a][b] = 0.0;
+  double *mixw = tables + 2 * kBiasCtx;    // [4][3]
+  for (int a = 0; a < 12; a++) mixw[a] = 0.0;
   double hin0 = 0, hin1 = 0, hin2 = 0;
   double hd0 = 0, hd1 = 0, hd2 = 0, hd3 = 0, hd4 = 0;
   double rmean = 0.0, rvar = 0.0;
@@ -52,7 +52,7 @@ SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *
     pt[0] = val[c0] / cnt[c0];
     pt[1] = val[c1] / cnt[c1];
     pt[2] = val[c2] / cnt[c2];
-    double *mw = mixw[mix_ctx];
+    double *mw = mixw + 3 * mix_ctx;
     const double pbias = dot_canon(pt, mw, 3);
     const double pd = px + pbias;
     // eprocess (libsac.cpp:105-109)

@@ -35,14 +35,16 @@ constexpr int kRlsMax = 10;
 
 template <int N> struct DArr { double v[N]; };
 
-// ---- serial mixer chain state (kept in LDS; wave 0 only, uniform)
-struct LmsChain {
-  double exw[2][5], exeg[2][5];   // LS_ADA experts: weights, squared-gradient EMAs
-  double smw[2], smrs[2];         // BlendExp weights and running scores
-  double S0, S1;                  // ALC
-  double p[5], ep[2], pred;
-};
-constexpr int kLmsChainDoubles = (int)(sizeof(LmsChain) / sizeof(double));
+// P-row dot of the RLS stage with a run-time order 1..10 but compile-time unrolling
+template <class A, class B>
+SA_HD double dot_canon_m(int m, A a, B b) {
+  switch (m) {
+    case 1: return dot_canon_n<1>(a, b); case 2: return dot_canon_n<2>(a, b); case 3: return dot_canon_n<3>(a, b);
+    case 4: return dot_canon_n<4>(a, b); case 5: return dot_canon_n<5>(a, b); case 6: return dot_canon_n<6>(a, b);
+    case 7: return dot_canon_n<7>(a, b); case 8: return dot_canon_n<8>(a, b); case 9: return dot_canon_n<9>(a, b);
+    default: return dot_canon_n<10>(a, b);
+  }
+}
 
 template <int NL, class C>
 struct LmsLds {
@@ -50,13 +52,15 @@ struct LmsLds {
   double *part;     // [2][NL/64][8]
   double *bc;       // [8]: wgrad[4], unused
   double *pin, *pout;
-  double *P, *rx, *rw, *rph;
-  double *chain;    // LmsChain (serial mixer state), only wave 0 touches it
+  double *rx, *rw, *rph;     // RLS history / weights mirror / P*x
+  double *pv;                // stage predictions p[0..4]
+  double *exwm;              // expert weights mirror [2][5]
+  double *cst;               // vmu[4], sum_powtab[4]
   int *sv;
   SA_HD static size_t bytes() {
     size_t d = 0;
     for (int s = 0; s < 4; s++) d += (size_t)C::slots(s) * NL + 1;
-    d += 2 * (NL / 64) * 8 + 8 + 2 * kLmsChunk + kRlsMax * kRlsMax + 3 * kRlsMax + kLmsChainDoubles;
+    d += 2 * (NL / 64) * 8 + 8 + 2 * kLmsChunk + 3 * kRlsMax + 8 + 10 + 8;
     return d * sizeof(double) + kLmsChunk * sizeof(int) + 16;
   }
   SA_HD void carve(char *base) {
@@ -65,8 +69,8 @@ struct LmsLds {
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 8;
     pin = d; d += kLmsChunk; pout = d; d += kLmsChunk;
-    P = d; d += kRlsMax * kRlsMax; rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
-    chain = d; d += kLmsChainDoubles;
+    rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
+    pv = d; d += 8; exwm = d; d += 10; cst = d; d += 8;
     sv = reinterpret_cast<int *>(d);
   }
 };
@@ -89,6 +93,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   const int m = p.lm_n;
 
   // ---- init: tables -> registers, zero rings / weights
+  // wave-0 lane roles of the mixer chain: lanes 0..9 = expert e=l/5, input i=l%5 (LS_ADA weight +
+  // squared-gradient EMA in registers); lanes 0..m-1 = row l of the RLS inverse covariance P.
+  typename E::template Reg<double> exw_r, exeg_r, rw_r, ph_r, xo_r, dots_r, spow_r;
+  typename E::template Reg<DArr<kRlsMax>> Prow;
   ex.par([&](int l) {
     const double *tp = tab;
     for (int s = 0; s < 4; s++) {
@@ -103,22 +111,17 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       tp += 2 * ns[s];
       for (int i = l; i < cap[s]; i += NL) L.ring[s][i] = 0.0;
     }
-    if (l < 8) L.bc[l] = 0.0;
-    for (int i = l; i < kRlsMax * kRlsMax; i += NL) L.P[i] = 0.0;
+    if (l < 8) { L.bc[l] = 0.0; L.pv[l] = 0.0; }
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (l == s) { L.cst[s] = p.vmu[s]; L.cst[4 + s] = sum_powtab[s]; }
+    if (l < 10) L.exwm[l] = 1.0 / 5;
     if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }
+    exw_r[l] = 1.0 / 5; exeg_r[l] = 0.0; rw_r[l] = 0.0; ph_r[l] = 0.0; xo_r[l] = 0.0; dots_r[l] = 0.0; spow_r[l] = 0.0;
+    for (int j = 0; j < kRlsMax; j++) Prow[l].v[j] = (j == l) ? 1.0 : 0.0;
   });
   ex.sync();
-  LmsChain &ch = *reinterpret_cast<LmsChain *>(L.chain);
-  ex.leader([&]() {
-    for (int i = 0; i < m; i++) L.P[i * m + i] = 1.0;
-    for (int e = 0; e < 2; e++) {
-      for (int i = 0; i < 5; i++) { ch.exw[e][i] = 1.0 / 5; ch.exeg[e][i] = 0.0; }
-      ch.smw[e] = 0.5; ch.smrs[e] = 0.0; ch.ep[e] = 0.0;
-    }
-    ch.S0 = ch.S1 = 0.0; ch.pred = 0.0;
-    for (int i = 0; i < 5; i++) ch.p[i] = 0.0;
-  });
-  ex.sync();
+  // uniform mixer state (wave 0)
+  double smw[2] = {0.5, 0.5}, smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0;
 
   const double lo = (double)p.lo, hi = (double)p.hi;
 
@@ -160,88 +163,100 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         if ((l & 63) == 0) for (int q = 0; q < 8; q++) L.part[(par * NW + (l >> 6)) * 8 + q] = acc[l].v[q];
       });
       ex.sync();
-      // ---- B: serial chain on wave 0
+      // ---- B: mixer chain on wave 0, lane-parallel where the algebra allows
+      ex.leader_par([&](int l) {
+        if (l < 4) {   // cross-wave totals of stage l, waves in order
+          double a = L.part[(par * NW) * 8 + l], b = L.part[(par * NW) * 8 + 4 + l];
+          for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + l]; b = b + L.part[(par * NW + w) * 8 + 4 + l]; }
+          dots_r[l] = a; spow_r[l] = b; L.pv[l] = a;
+        }
+      });
+      ex.wsync();
+      double target = 0.0, rpx = 0.0, ep[2] = {0, 0}, pred = 0.0, bp[5] = {0, 0, 0, 0, 0}, pl[5] = {0, 0, 0, 0, 0};
       ex.leader([&]() {
-        double dots[4], spow[4];
-        for (int q = 0; q < 4; q++) {
-          double a = L.part[(par * NW) * 8 + q], b = L.part[(par * NW) * 8 + 4 + q];
-          for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + q]; b = b + L.part[(par * NW + w) * 8 + 4 + q]; }
-          dots[q] = a; spow[q] = b;
-        }
         const double plpc = L.pin[tt];
-        const double target = (double)L.sv[tt] - plpc;
-        // Cascade::Predict
-        for (int i = 0; i < 4; i++) ch.p[i] = dots[i];
-        const double rpx = dot_canon(L.rx, L.rw, m);
-        ch.p[4] = rpx;
-        for (int e = 0; e < 2; e++) ch.ep[e] = dot_canon(ch.p, ch.exw[e], 5);
-        ch.pred = dot_canon(ch.ep, ch.smw, 2);
-        L.pout[tt] = plpc + ch.pred;
-        // Cascade::Update(target)
-        double bp[5];
+        target = (double)L.sv[tt] - plpc;
+        // Cascade::Predict (cascade.h:93-100)
+        rpx = dot_canon(L.rx, L.rw, m);
+        for (int i = 0; i < 4; i++) pl[i] = L.pv[i];
+        pl[4] = rpx;
+        for (int e = 0; e < 2; e++) ep[e] = dot_canon_n<5>([&](int i) { return pl[i]; }, [&](int i) { return L.exwm[5 * e + i]; });
+        pred = dot_canon_n<2>([&](int i) { return i ? ep[1] : ep[0]; }, [&](int i) { return i ? smw[1] : smw[0]; });
+        L.pout[tt] = plpc + pred;
+        // Cascade::Update(target): stage targets (cascade.h:101-112)
         double p_prefix = 0.0;
+#pragma unroll
         for (int i = 0; i <= 4; i++) {
-          const double ew[2] = {ch.exw[0][i], ch.exw[1][i]};
-          const double wgt = fmax(dot_canon(ew, ch.smw, 2), 0.0);
-          const double px = fma(1.0 - p.proj_alpha, p_prefix, p.proj_alpha * ch.pred);
+          const double ew0 = L.exwm[i], ew1 = L.exwm[5 + i];
+          const double wgt = fmax(dot_canon_n<2>([&](int q) { return q ? ew1 : ew0; }, [&](int q) { return q ? smw[1] : smw[0]; }), 0.0);
+          const double px = fma(1.0 - p.proj_alpha, p_prefix, p.proj_alpha * pred);
           bp[i] = target - clampd(px, lo, hi);
-          p_prefix = fma(wgt, ch.p[i], p_prefix);
+          p_prefix = fma(wgt, pl[i], p_prefix);
         }
-        for (int s = 0; s < 4; s++) {
-          // NLMS_Stream::Update scalar part (ls.h:47-48)
-          L.bc[s] = p.vmu[s] * (bp[s] - dots[s]) * sum_powtab[s] / (spow[s] + 1.0);
-          int np = pos[s] - 1; if (np < 0) np += cap[s];
-          L.ring[s][np] = bp[s];
-        }
-        // RLS::UpdateHist(bp[4]) (rls.cpp:28-65)
-        {
-          const double val = bp[4];
-          const double err = val - rpx;
-          for (int i = 0; i < m; i++) L.rph[i] = dot_canon(&L.P[i * m], L.rx, m);
-          const double phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8);
-          const double err2 = err * err;
-          const double R = fmax(ch.S0 - ch.S1, 1e-5);
-          const double nis = err2 / (phi + R);
-          const double mm = sa_exp(-p.lm_alpha * nis);
-          const double alpha = fma(0.999 - 0.99, mm, 0.99);
-          const double denom = 1. / (alpha + phi);
-          const double inv_alpha = 1.0 / alpha;
-          for (int i = 0; i < m; i++)
-            for (int j = 0; j <= i; j++) {
-              const double pm = L.rph[i] * L.rph[j];
-              const double v = fma(-denom, pm, L.P[i * m + j]) * inv_alpha;
-              L.P[i * m + j] = v; L.P[j * m + i] = v;
-            }
-          for (int i = 0; i < m; i++) L.rw[i] = fma(err, denom * L.rph[i], L.rw[i]);
-          ch.S0 = fma(0.95, ch.S0, (1.0 - 0.95) * err2);
-          ch.S1 = fma(0.95, ch.S1, (1.0 - 0.95) * phi);
-          for (int i = m - 1; i > 0; i--) L.rx[i] = L.rx[i - 1];
-          if (m > 0) L.rx[0] = val;
-        }
-        // BlendLS::Update: experts (L1 then L2), then BlendExp
-        for (int e = 0; e < 2; e++) {
-          const double error = target - ch.ep[e];
-          const double loss = (e == 0) ? sgnd(error) : error;
+      });
+      ex.leader_par([&](int l) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          if (l == s) {   // NLMS_Stream::Update scalar part (ls.h:47-48) + history push, stage s on lane s
+            L.bc[s] = L.cst[s] * (bp[s] - dots_r[l]) * L.cst[4 + s] / (spow_r[l] + 1.0);
+            int np = pos[s] - 1; if (np < 0) np += cap[s];
+            L.ring[s][np] = bp[s];
+          }
+        if (l < 10) {  // LS_ADA experts (ls.h:224-236): expert e = l/5 (0: L1 loss, 1: L2), input i = l%5
+          const int e = l >= 5, i = l - 5 * e;
+          const double error = target - (e ? ep[1] : ep[0]);
+          const double loss = e ? error : sgnd(error);
+          const double pi_ = i == 0 ? pl[0] : (i == 1 ? pl[1] : (i == 2 ? pl[2] : (i == 3 ? pl[3] : pl[4])));
+          const double grad = loss * pi_;
           const double beta = p.mu_mix_beta, beta1 = 1.0 - p.mu_mix_beta;
-          for (int i = 0; i < 5; i++) {
-            const double grad = loss * ch.p[i];
-            ch.exeg[e][i] = fma(beta, ch.exeg[e][i], beta1 * grad * grad);
-            const double mu_scaled = p.mu_mix / (sqrt(ch.exeg[e][i]) + 1e-5);
-            ch.exw[e][i] = fma(mu_scaled, grad, ch.exw[e][i]);
-          }
+          exeg_r[l] = fma(beta, exeg_r[l], beta1 * grad * grad);
+          const double mu_scaled = p.mu_mix / (sqrt(exeg_r[l]) + 1e-5);
+          exw_r[l] = fma(mu_scaled, grad, exw_r[l]);
         }
-        {
-          double zm[2];
-          for (int e = 0; e < 2; e++) {
-            const double loss = fabs(target - ch.ep[e]);
-            ch.smrs[e] = fma(0.95, ch.smrs[e], (1.0 - 0.95) * (-loss));
-            zm[e] = 1.0 * ch.smrs[e];
-          }
-          const double maxz = fmax(zm[0], zm[1]);
-          const double w0 = sa_exp(zm[0] - maxz), w1 = sa_exp(zm[1] - maxz);
-          const double inv = 1.0 / (w0 + w1);
-          ch.smw[0] = w0 * inv; ch.smw[1] = w1 * inv;
+        if (l < m) {   // RLS: ph = P x, row l (rls.cpp:33)
+          ph_r[l] = dot_canon_m(m, [&](int j) { return Prow[l].v[j]; }, [&](int j) { return L.rx[j]; });
+          L.rph[l] = ph_r[l];
         }
+      });
+      ex.wsync();
+      double denom = 0.0, inv_alpha = 0.0, rerr = 0.0;
+      ex.leader([&]() {   // RLS::Update scalars + ALC (rls.cpp:28-46, rls.h:21-39)
+        rerr = bp[4] - rpx;
+        const double phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8);
+        const double err2 = rerr * rerr;
+        const double R = fmax(S0 - S1, 1e-5);
+        const double nis = err2 / (phi + R);
+        const double mm = sa_exp(-p.lm_alpha * nis);
+        const double alpha = fma(0.999 - 0.99, mm, 0.99);
+        denom = 1. / (alpha + phi);
+        inv_alpha = 1.0 / alpha;
+        S0 = fma(0.95, S0, (1.0 - 0.95) * err2);
+        S1 = fma(0.95, S1, (1.0 - 0.95) * phi);
+        // BlendExp<RunSumEMA>::Update (blend.h:31-90)
+        double zm[2];
+        for (int e = 0; e < 2; e++) {
+          const double loss = fabs(target - ep[e]);
+          smrs[e] = fma(0.95, smrs[e], (1.0 - 0.95) * (-loss));
+          zm[e] = 1.0 * smrs[e];
+        }
+        const double maxz = fmax(zm[0], zm[1]);
+        const double w0 = sa_exp(zm[0] - maxz), w1 = sa_exp(zm[1] - maxz);
+        const double inv = 1.0 / (w0 + w1);
+        smw[0] = w0 * inv; smw[1] = w1 * inv;
+      });
+      ex.leader_par([&](int l) {
+        if (l < 10) L.exwm[l] = exw_r[l];
+        if (l < m) {   // P / w update of row l (rls.cpp:47-56); both triangles get the same bits
+#pragma unroll
+          for (int j = 0; j < kRlsMax; j++)
+            if (j < m) Prow[l].v[j] = fma(-denom, ph_r[l] * L.rph[j], Prow[l].v[j]) * inv_alpha;
+          rw_r[l] = fma(rerr, denom * ph_r[l], rw_r[l]);
+          xo_r[l] = l > 0 ? L.rx[l - 1] : 0.0;
+        }
+      });
+      ex.wsync();
+      ex.leader_par([&](int l) {
+        if (l < m) { L.rw[l] = rw_r[l]; L.rx[l] = l == 0 ? bp[4] : xo_r[l]; }   // RollBack(x, val), rls.cpp:64
       });
       for (int s = 0; s < 4; s++) { pos[s] -= 1; if (pos[s] < 0) pos[s] += cap[s]; }
       ex.sync();

@@ -177,4 +177,168 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path for one-wave workgroups (E::nl == 64, n_ols <= 64).  Same arithmetic as ols_stage
+// (bit-identical results); what changes is where values live and how they travel:
+//  * x, b, w, the forward/backward-solve vectors: one element per lane in registers, moved with
+//    v_readlane broadcasts instead of LDS round trips + barriers;
+//  * LDL^T column step: the pivot is always produced by lane 0's first trailing element, so it is
+//    handed on in a register; scaling of the column and the trailing update share one phase
+//    (the scaled column goes to a second triangle, Lk), leaving one barrier per column;
+//  * the element loops issue their LDS loads four elements at a time.
+struct OlsLdsFast {
+  double *X, *Wv, *M, *Wk, *Lk;
+  unsigned short *tab;
+  SA_HD static size_t bytes(int nmax) {
+    return (size_t)(2 * nmax + 3 * tri_count(nmax)) * sizeof(double) + (size_t)(tri_count(nmax) + 8) * 2 + 16;
+  }
+  SA_HD void carve(char *base, int nmax) {
+    double *d = reinterpret_cast<double *>(base);
+    X = d; d += nmax; Wv = d; d += nmax;
+    M = d; d += tri_count(nmax); Wk = d; d += tri_count(nmax); Lk = d; d += tri_count(nmax);
+    tab = reinterpret_cast<unsigned short *>(d);
+  }
+};
+
+template <class E>
+SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int *other, int n,
+                          double *p_out, char *lds_base, int nmax) {
+  static_assert(E::nl == 64, "one-wave path");
+  constexpr int NL = 64;
+  const int no = p.n_ols;
+  const int ntri = tri_count(no);
+  OlsLdsFast L;
+  L.carve(lds_base, nmax);
+
+  typename E::template Reg<double> breg, wreg, sreg, zreg, areg, dreg, invd_mine;
+  typename E::template Reg<int> xnext;
+
+  ex.par([&](int l) {
+    breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; dreg[l] = 0.0; invd_mine[l] = 0.0;
+    if (l < no) { L.X[l] = 0.0; L.Wv[l] = 0.0; }
+    for (int e = l; e < ntri; e += NL) { L.M[e] = 0.0; L.Wk[e] = 0.0; L.Lk[e] = 0.0; }
+    for (int j = l; j < no; j += NL) {
+      const int o = tri_off(no, j);
+      for (int i = j; i < no; i++) L.tab[o + (i - j)] = (unsigned short)((i << 8) | j);
+    }
+    xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
+  });
+  ex.sync();
+
+  double esum = 0.0;
+  int km = 0;
+  const double lambda = p.lambda, nu = p.nu_eff;
+  const double one_m_lambda = 1.0 - lambda;
+
+  for (int t = 0; t < n; t++) {
+    ex.par([&](int l) {
+      if (l < no) L.X[l] = (double)xnext[l];
+      if (l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
+    });
+    ex.sync();
+    double pred = 0.0, val = 0.0, ff = 0.0;
+    ex.uni([&]() {
+      pred = dot_canon(L.X, L.Wv, no);
+      val = (double)self[t];
+      const double e = val - pred;
+      esum = fma(p.beta_sum, esum, fabs(e));
+      const double c = sa_pow(esum + p.beta_add, -p.beta_pow);
+      ff = one_m_lambda * c;
+    });
+    ex.par([&](int l) { if (l == 0) p_out[t] = pred; });
+    km++;
+    const bool solve = km >= p.k;
+    // covariance / rhs update; when a solve follows, also seed the LDL^T workspace
+    ex.par([&](int l) {
+      for (int e0 = l; e0 < ntri; e0 += 4 * NL) {
+        int ij[4]; double m[4], xr[4], xc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int e = e0 + u * NL; ij[u] = e < ntri ? L.tab[e] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int e = e0 + u * NL; m[u] = e < ntri ? L.M[e] : 0.0; xr[u] = L.X[ij[u] >> 8]; xc[u] = L.X[ij[u] & 255]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = e0 + u * NL;
+          if (e < ntri) {
+            const double v = fma(lambda, m[u], ff * (xr[u] * xc[u]));
+            L.M[e] = v;
+            if (solve) {
+              const double w = ((ij[u] >> 8) == (ij[u] & 255)) ? v + nu : v;
+              L.Wk[e] = w;
+              if (e == 0) dreg[l] = w;
+            }
+          }
+        }
+      }
+      if (l < no) breg[l] = fma(lambda, breg[l], ff * (L.X[l] * val));
+    });
+    if (solve) {
+      km = 0;
+      ex.sync();
+      bool ok = true;
+      for (int kk = 0; kk < no; kk++) {
+        const int ok0 = tri_off(no, kk);
+        const double dk = ex.lane_bcast(dreg, 0);
+        if (dk < 1e-12) { ok = false; break; }
+        const double invd = 1.0 / dk;
+        const int e0 = tri_off(no, kk + 1);
+        ex.par([&](int l) {
+          if (l == kk) invd_mine[l] = invd;
+          // scaled column kk -> Lk (rows kk+1..no-1)
+          for (int i = kk + 1 + l; i < no; i += NL) L.Lk[ok0 + (i - kk)] = L.Wk[ok0 + (i - kk)] * invd;
+          // trailing update of every element (i,j), j > kk
+          for (int eb = e0 + l; eb < ntri; eb += 4 * NL) {
+            int ij[4]; double li[4], lj[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int e = eb + u * NL; ij[u] = e < ntri ? L.tab[e] : ((kk + 1) << 8 | (kk + 1)); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int e = eb + u * NL;
+              li[u] = L.Wk[ok0 + ((ij[u] >> 8) - kk)]; lj[u] = L.Wk[ok0 + ((ij[u] & 255) - kk)];
+              w[u] = e < ntri ? L.Wk[e] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int e = eb + u * NL;
+              if (e < ntri) {
+                const int j = ij[u] & 255;
+                const double tt = (li[u] * invd) * (lj[u] * invd);
+                const double r = fold_fused(kk, j) ? fma(-tt, dk, w[u]) : w[u] - tt * dk;
+                L.Wk[e] = r;
+                if (e == e0) dreg[l] = r;      // next pivot: lane 0, first element
+              }
+            }
+          }
+        });
+        ex.sync();
+      }
+      if (ok) {
+        // forward solve: column sweep with register broadcasts
+        ex.par([&](int l) { sreg[l] = breg[l]; });
+        for (int kk = 0; kk + 1 < no; kk++) {
+          const double yk = ex.lane_bcast(sreg, kk);
+          const int ok0 = tri_off(no, kk);
+          ex.par([&](int l) {
+            if (l > kk && l < no) {
+              const double lv = L.Lk[ok0 + (l - kk)];
+              sreg[l] = fold_fused(kk, l) ? fma(-lv, yk, sreg[l]) : sreg[l] - lv * yk;
+            }
+          });
+        }
+        ex.par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
+        // backward solve: strictly serial fused chains, operands broadcast from registers
+        for (int i = no - 1; i >= 0; --i) {
+          const int oi = tri_off(no, i);
+          ex.par([&](int l) { if (l > i && l < no) areg[l] = -L.Lk[oi + (l - i)]; });
+          double s = ex.lane_bcast(zreg, i);
+          for (int kk = i + 1; kk < no; ++kk) s = fma(ex.lane_bcast(areg, kk), ex.lane_bcast(wreg, kk), s);
+          ex.par([&](int l) { if (l == i) wreg[l] = s; });
+        }
+        ex.par([&](int l) { if (l < no) L.Wv[l] = wreg[l]; });
+      }
+    }
+    ex.sync();
+  }
+}
+
 }  // namespace sacamd

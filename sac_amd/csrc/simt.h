@@ -41,6 +41,13 @@ struct ExecEmu {
   template <class F> void leader(F &&f) { f(); }
   void sync() {}
   template <class T> T lane_get(const Reg<T> &r, int k) { return r[k]; }
+  double lane_bcast(const Reg<double> &r, int k) { return r[k]; }
+  int lane_geti(const Reg<int> &r, int k) { return r[k]; }
+  // code only lane 0 executes: run once
+  template <class F> void lane0(F &&f) { f(); }
+  // per-lane code of wave 0 only; wsync orders LDS traffic inside one wave
+  template <class F> void leader_par(F &&f) { for (int l = 0; l < (NL < 64 ? NL : 64); l++) f(l); }
+  void wsync() {}
   // butterfly sum of K values per lane within each 64-lane wave (all lanes get the wave total)
   template <int K, class R> void wave_sum(R &r) {
     constexpr int W = NL < 64 ? NL : 64;
@@ -92,6 +99,16 @@ struct ExecDev {
     }
   }
   template <class T> SA_D T lane_get(const Reg<T> &r, int k) { return __shfl(r.v, k, 64); }
+  SA_D int lane_geti(const Reg<int> &r, int k) { return __builtin_amdgcn_readlane(r.v, k); }
+  template <class F> SA_D void lane0(F &&f) { if (threadIdx.x == 0) f(); }
+  template <class F> SA_D void leader_par(F &&f) { if (threadIdx.x < 64) f((int)threadIdx.x); }
+  SA_D void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  // value of lane k (k uniform across the wave) -> scalar broadcast via v_readlane_b32
+  SA_D double lane_bcast(const Reg<double> &r, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(r.v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(r.v), k);
+    return __hiloint2double(hi, lo);
+  }
   SA_D void allsum(Reg<double> &r, double *scratch) {
     constexpr int W = NL < 64 ? NL : 64;
     double v = r.v;

@@ -38,9 +38,8 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     double *pl = plpc + (size_t)ch_self * n, *ps = psum + (size_t)ch_self * n;
     if (p.n_ols > kMaxOLS) return -1;
     {
-      std::vector<char> lds(OlsLds::bytes(p.n_ols <= 64 ? 64 : 128));
-      if (p.n_ols <= 64) { ExecEmu<64> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 64); }
-      else { ExecEmu<128> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 128); }
+      if (p.n_ols <= 64) { std::vector<char> lds(OlsLdsFast::bytes(64)); ExecEmu<64> ex; ols_stage_fast(ex, p, self, other, n, pl, lds.data(), 64); }
+      else { std::vector<char> lds(OlsLds::bytes(128)); ExecEmu<128> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 128); }
     }
     std::vector<double> tab; double sp[4];
     for (int s = 0; s < 4; s++) {
@@ -80,13 +79,13 @@ static void host_laplace(std::vector<unsigned short> &lap, unsigned short *plap)
 API int emu_bitplane(const int32_t *s2u, int n, int maxbpn, const unsigned char *used, const int *fwd_i, const int *inv_i, unsigned char *out, int cap) {
   static std::vector<unsigned short> lap; static unsigned short plap[32];
   if (lap.empty()) host_laplace(lap, plap);
-  std::vector<short> gf(kPScale), lf(kPScale); std::vector<unsigned short> gi(4095), li(4095);
+  std::vector<short> gf(kPScale); std::vector<unsigned short> gi(4095);
   for (int i = 0; i < kPScale; i++) gf[i] = (short)fwd_i[i];
   for (int i = 0; i < 4095; i++) gi[i] = (unsigned short)inv_i[i];
   std::vector<CntL> csig0(65536);
-  CoderModel *M = new CoderModel; CoderDesc *D = new CoderDesc; CoderWin *W = new CoderWin; MapModel *MM = new MapModel;
+  CoderModel *M = new CoderModel; CoderTabs *T = new CoderTabs; CoderWin *W = new CoderWin; MapModel *MM = new MapModel;
   ExecEmu<64> ex;
-  int len = coder_stream(ex, s2u, n, maxbpn, used, lap.data(), gf.data(), gi.data(), plap, csig0.data(), out, cap, *M, *D, *W, *MM, lf.data(), li.data());
-  delete M; delete D; delete W; delete MM;
+  int len = coder_stream(ex, s2u, n, maxbpn, used, lap.data(), gf.data(), gi.data(), plap, csig0.data(), out, cap, *M, *T, *W, *MM);
+  delete M; delete T; delete W; delete MM;
   return len;
 }
