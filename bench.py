@@ -44,22 +44,34 @@ def make_batch(nframes, seconds, seed0):
     return frames, np.ascontiguousarray(il), n
 
 
+def shard_frames(total_frames, rank, world):
+    """Frames of a corpus are independent units (--opt-reset): contiguous block per rank."""
+    per = (total_frames + world - 1) // world
+    lo = min(rank * per, total_frames)
+    return list(range(lo, min(lo + per, total_frames)))
+
+
 def gather_records(recs, rank, world, device):
-    """Variable-length gather of frame records to rank 0 over RCCL (lengths, then padded payloads)."""
+    """Variable-length gather of frame records to rank 0 (RCCL on GPUs, gloo in the CPU tests):
+    all_gather of the per-frame lengths, then one gather of the padded payloads."""
     import torch
     import torch.distributed as dist
 
     blob = b"".join(recs)
-    lens = torch.tensor([len(r) for r in recs], dtype=torch.int64, device=device)
+    meta = torch.tensor([len(recs), len(blob)], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)                     # ranks may hold different numbers of frames
+    max_n = int(max(int(m[0].item()) for m in metas))
+    mx = int(max(int(m[1].item()) for m in metas))
+    lens = torch.zeros(max_n, dtype=torch.int64, device=device)
+    lens[: len(recs)] = torch.tensor([len(r) for r in recs], dtype=torch.int64)
     all_lens = [torch.zeros_like(lens) for _ in range(world)]
     dist.all_gather(all_lens, lens)
-    tot = torch.tensor([len(blob)], dtype=torch.int64, device=device)
-    tots = [torch.zeros_like(tot) for _ in range(world)]
-    dist.all_gather(tots, tot)
-    mx = int(max(int(t.item()) for t in tots))
-    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
-    buf[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
-    out = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+    tots = [m[1:2] for m in metas]
+    buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=device)
+    if blob:
+        buf[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, out, dst=0)
     if rank != 0:
         return None
@@ -67,7 +79,7 @@ def gather_records(recs, rank, world, device):
     for r in range(world):
         b = out[r][: int(tots[r].item())].cpu().numpy().tobytes()
         o = 0
-        for ln in all_lens[r].tolist():
+        for ln in all_lens[r].tolist()[: int(metas[r][0].item())]:
             res.append(b[o: o + ln]); o += ln
     return res
 

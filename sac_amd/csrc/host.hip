@@ -19,6 +19,7 @@
 
 #include "../../include/sac_amd.h"
 #include "coder.h"
+#include "dds_host.h"
 #include "kernels.h"
 #include "params.h"
 
@@ -29,7 +30,6 @@ using namespace sacamd;
 namespace {
 
 // ---------------------------------------------------------------- default profile (profile.cpp:3-89)
-struct Coef { float vmin, vmax, vdef; };
 static void load_base_profile(Coef *c) {
   const int mo = 32, wb = 13;
   auto S = [&](int i, double a, double b, double d) { c[i] = {(float)a, (float)b, (float)d}; };

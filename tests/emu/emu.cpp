@@ -89,3 +89,47 @@ API int emu_bitplane(const int32_t *s2u, int n, int maxbpn, const unsigned char 
   delete M; delete T; delete W; delete MM;
   return len;
 }
+
+// ---------------------------------------------------------------- host DDS logic (product code) on a test function
+#include "../../sac_amd/csrc/dds_host.h"
+API double emu_dds_quadratic(int ndim, const double *xmin, const double *xmax, const double *xstart, const double *center,
+                             int nfunc_max, int num_threads, double sigma, double *xbest, double *trace_cost) {
+  std::vector<Coef> box(ndim); std::vector<int> lp(ndim);
+  for (int i = 0; i < ndim; i++) { box[i] = {(float)xmin[i], (float)xmax[i], 0.f}; lp[i] = i; }
+  int ne = 0;
+  auto f = [&](const std::vector<double> &x) {
+    double s = 0;
+    for (int i = 0; i < ndim; i++) { double d = x[i] - center[i]; s += (i + 1) * d * d; }
+    if (trace_cost && ne < nfunc_max) trace_cost[ne] = s;
+    ne++;
+    return s;
+  };
+  FrameSearch fs; fs.sigma = sigma; fs.xb.assign(xstart, xstart + ndim); fs.cb = f(fs.xb);
+  while (fs.nfunc < nfunc_max) {
+    const int nt = num_threads <= 0 ? 1 : std::min(nfunc_max - fs.nfunc, num_threads);
+    fs.gen.clear();
+    for (int i = 0; i < nt; i++) { fs.gen.push_back(fs.candidate(box.data(), lp, nfunc_max)); fs.nfunc++; }
+    std::vector<double> gc(nt);
+    for (int i = 0; i < nt; i++) gc[i] = f(fs.gen[i]);
+    if (num_threads <= 0) fs.select_single(gc[0]); else fs.select_mt(gc.data(), nt);
+  }
+  for (int i = 0; i < ndim; i++) xbest[i] = fs.xb[i];
+  return fs.cb;
+}
+
+// ---------------------------------------------------------------- libm port vs the host libm
+#include <random>
+API long emu_libm_mismatches(long n, int seed) {
+  std::mt19937_64 g(seed); std::uniform_real_distribution<double> U(0, 1);
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    double x = (i & 1) ? -U(g) * 760 : (U(g) - 0.5) * 100;
+    if ((i % 7) == 0) x = -U(g) * 1e-3;
+    volatile double a = std::exp(x); if (sa_asu(a) != sa_asu(sa_exp(x))) bad++;
+    double px, py; const int m = i % 4;
+    if (m == 0) { px = 0.1 + U(g) * 1e5; py = -(0.1 + U(g) * 1.9); } else if (m == 1) { px = 1 + (double)(g() % 8192); py = U(g); }
+    else if (m == 2) { px = 0.98 + U(g) * 0.02; py = (double)(g() % 8192); } else { px = std::exp((U(g) - 0.5) * 20); py = (U(g) - 0.5) * 40; }
+    volatile double b = std::pow(px, py); if (sa_asu(b) != sa_asu(sa_pow(px, py))) bad++;
+  }
+  return bad;
+}
