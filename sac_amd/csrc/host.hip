@@ -82,6 +82,8 @@ struct TimedSpan { int fam; hipEvent_t a, b; };
 struct sacamd_ctx {
   int device = 0, nch = 0, max_framesize = 0, max_frames = 0;
   hipStream_t stream = nullptr;
+  hipStream_t cls_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // concurrent kernel classes
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::string err;
   // staged batch
   int nframes = 0, framesize = 0;
@@ -185,7 +187,7 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
       if (p.lm_n < 1 || p.lm_n > 10) return fail(c, SACAMD_ERR_ARG, "RLS order outside [1,10]");
       for (int s = 0; s < 4; s++)
         if (p.vn[s] < 1 || p.vn[s] > (8192 >> s)) return fail(c, SACAMD_ERR_ARG, "NLMS stage length outside the profile box");
-      it.ols_class = p.n_ols <= 32 ? 0 : (p.n_ols <= 64 ? 1 : 2);
+      it.ols_class = p.n_ols <= 16 ? 0 : (p.n_ols <= 32 ? 1 : (p.n_ols <= 64 ? 2 : 3));
       const int *vn = p.vn;
       it.lms_class = (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) ? 0
                    : (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) ? 1 : 2;
@@ -214,13 +216,13 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
   HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
   // class lists, heaviest first
-  std::vector<int> idx_ols[3], idx_lms[3];
+  std::vector<int> idx_ols[4], idx_lms[3];
   for (int i = 0; i < count; i++) { idx_ols[items[i].ols_class].push_back(i); idx_lms[items[i].lms_class].push_back(i); }
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
   std::vector<int> flat;
-  int base_ols[3], base_lms[3];
-  for (int k = 0; k < 3; k++) {
+  int base_ols[4], base_lms[3];
+  for (int k = 0; k < 4; k++) {
     std::stable_sort(idx_ols[k].begin(), idx_ols[k].end(), [&](int a, int b) { return olsw(a) > olsw(b); });
     base_ols[k] = (int)flat.size(); flat.insert(flat.end(), idx_ols[k].begin(), idx_ols[k].end());
   }
@@ -230,10 +232,24 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   }
   HIPCHK(c, hipMemcpyAsync(c->d_idx.p, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, c->stream));
   { Span sp(c, FAM_TABLES); launch_tables(c->stream, c->d_items.p, count, c->d_tab.p); }
+  // the classes of one stage are independent kernels: fork them onto side streams so that the
+  // (latency-bound, low-occupancy) launches overlap; the stage boundary is a join on the main stream
+  auto fork_join = [&](int nclass, auto &&launch_class) -> int {
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int k = 0; k < nclass; k++) {
+      HIPCHK(c, hipStreamWaitEvent(c->cls_stream[k], c->ev_fork, 0));
+      launch_class(k, c->cls_stream[k]);
+      HIPCHK(c, hipEventRecord(c->ev_join[k], c->cls_stream[k]));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
+    }
+    return 0;
+  };
   { Span sp(c, FAM_OLS);
-    for (int k = 0; k < 3; k++) launch_ols(c->stream, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); }
+    int r = fork_join(4, [&](int k, hipStream_t st) { launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); });
+    if (r) return r; }
   { Span sp(c, FAM_LMS);
-    for (int k = 0; k < 3; k++) launch_lms(c->stream, c->d_items.p, c->d_idx.p + base_lms[k], (int)idx_lms[k].size(), k, view(c), c->d_tab.p, c->d_p.p); }
+    int r = fork_join(3, [&](int k, hipStream_t st) { launch_lms(st, c->d_items.p, c->d_idx.p + base_lms[k], (int)idx_lms[k].size(), k, view(c), c->d_tab.p, c->d_p.p); });
+    if (r) return r; }
   { Span sp(c, FAM_BIAS);
     launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
   HIPCHK(c, hipGetLastError());
@@ -282,6 +298,10 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   sacamd_ctx *c = new sacamd_ctx();
   c->device = device; c->nch = nch; c->max_framesize = max_framesize; c->max_frames = max_frames;
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
+  for (int k = 0; k < 4; k++) {
+    if (hipStreamCreate(&c->cls_stream[k]) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
+  }
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   c->ch_stride = ((long long)max_framesize + 63) / 64 * 64;
   c->frame_stride = c->ch_stride * nch;
   const size_t tot = (size_t)c->frame_stride * max_frames;
@@ -298,6 +318,8 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); (void)hipStreamDestroy(c->stream); }
+  for (int k = 0; k < 4; k++) { if (c->cls_stream[k]) (void)hipStreamDestroy(c->cls_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
   c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_cost.release();
@@ -534,15 +556,16 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
   for (int i = 0; i < count; i++) {
     HIPCHK(c, hipMemcpyAsync(c->d_idx.p, &i, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p);
+    { Span sp(c, FAM_OLS); launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (plpc) HIPCHK(c, hipMemcpy(plpc + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, view(c), c->d_tab.p, c->d_p.p);
+    { Span sp(c, FAM_LMS); launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, view(c), c->d_tab.p, c->d_p.p); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
   }
-  launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, c->d_pred.p);
+  { Span sp(c, FAM_BIAS); launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, c->d_pred.p); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  collect_spans(c);
   HIPCHK(c, hipGetLastError());
   for (int i = 0; i < count; i++) {
     if (err) HIPCHK(c, hipMemcpy(err + (size_t)items[i].ch_self * n, c->d_err.p + items[i].off_err, sizeof(int) * n, hipMemcpyDeviceToHost));

@@ -55,19 +55,20 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   else ols_stage(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
 }
 
+template <int NL, int NMAX>
+static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
+  static bool once = false;
+  const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : OlsLds::bytes(NMAX);
+  if (!once) { (void)hipFuncSetAttribute((const void *)k_ols<NL, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); once = true; }
+  hipLaunchKernelGGL((k_ols<NL, NMAX>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_p);
+}
+
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p) {
   if (count <= 0) return;
-  if (ols_class == 0) {
-    hipLaunchKernelGGL((k_ols<64, 32>), dim3(count), dim3(64), OlsLdsFast::bytes(32), s, d_items, d_idx, v, d_p);
-  } else if (ols_class == 1) {
-    static bool once64 = false;
-    if (!once64) { hipFuncSetAttribute((const void *)k_ols<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OlsLdsFast::bytes(64)); once64 = true; }
-    hipLaunchKernelGGL((k_ols<64, 64>), dim3(count), dim3(64), OlsLdsFast::bytes(64), s, d_items, d_idx, v, d_p);
-  } else {
-    static bool once = false;
-    if (!once) { hipFuncSetAttribute((const void *)k_ols<128, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OlsLds::bytes(96)); once = true; }
-    hipLaunchKernelGGL((k_ols<128, 96>), dim3(count), dim3(128), OlsLds::bytes(96), s, d_items, d_idx, v, d_p);
-  }
+  if (ols_class == 0) launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p);
+  else if (ols_class == 1) launch_ols_c<64, 32>(s, d_items, d_idx, count, v, d_p);
+  else if (ols_class == 2) launch_ols_c<64, 64>(s, d_items, d_idx, count, v, d_p);
+  else launch_ols_c<128, 96>(s, d_items, d_idx, count, v, d_p);
 }
 
 // ------------------------------------------------------------------ stage 2: cascade

@@ -49,7 +49,7 @@ SA_HD double sa_exp_special(double tmp, unsigned long long sbits, unsigned long 
 }
 
 // shared core of exp(x) and pow's exp_inline(x, xtail)
-SA_HD double sa_exp_core(double x, double xtail, bool standalone) {
+SA_HD double sa_exp_core(double x, double xtail, bool standalone, const unsigned long long *exptab) {
   unsigned abstop = (unsigned)(sa_asu(x) >> 52) & 0x7ff;
   if (abstop - 0x3c9u >= 0x408u - 0x3c9u) {
     if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;
@@ -69,8 +69,8 @@ SA_HD double sa_exp_core(double x, double xtail, bool standalone) {
   if (!standalone) r += xtail;
   const unsigned long long idx = 2 * (ki % 128);
   const unsigned long long top = ki << (52 - 7);
-  const double tail = sa_asd(kExpTab[idx]);
-  const unsigned long long sbits = kExpTab[idx + 1] + top;
+  const double tail = sa_asd(exptab[idx]);
+  const unsigned long long sbits = exptab[idx + 1] + top;
   const double r2 = r * r;
   const double tmp = fma(r2 * r2, fma(r, kExpPoly[3], kExpPoly[2]), fma(r2, fma(r, kExpPoly[1], kExpPoly[0]), tail + r));
   if (abstop == 0) return sa_exp_special(tmp, sbits, ki);
@@ -78,9 +78,12 @@ SA_HD double sa_exp_core(double x, double xtail, bool standalone) {
   return fma(scale, tmp, scale);
 }
 
-SA_HD double sa_exp(double x) { return sa_exp_core(x, 0.0, true); }
+SA_HD double sa_exp(double x) { return sa_exp_core(x, 0.0, true, kExpTab); }
+// same, with the 2 KB table staged by the caller (LDS)
+SA_HD double sa_exp_t(double x, const unsigned long long *exptab) { return sa_exp_core(x, 0.0, true, exptab); }
 
-SA_HD double sa_pow(double x, double y) {
+// logtab: 128 x {invc, logc, logctail}; exptab: 256 words
+SA_HD double sa_pow_t(double x, double y, const double *logtab, const unsigned long long *exptab) {
   const unsigned long long ix = sa_asu(x), iy = sa_asu(y);
   const unsigned topy = (unsigned)(iy >> 52) & 0x7ff;
   if (2 * iy == 0) return 1.0;
@@ -96,7 +99,7 @@ SA_HD double sa_pow(double x, double y) {
   const int k = (int)((long long)tmp >> 52);
   const unsigned long long iz = ix - (tmp & (0xfffULL << 52));
   const double z = sa_asd(iz), kd = (double)k;
-  const double invc = kPowLogTab[3 * i], logc = kPowLogTab[3 * i + 1], logctail = kPowLogTab[3 * i + 2];
+  const double invc = logtab[3 * i], logc = logtab[3 * i + 1], logctail = logtab[3 * i + 2];
   const double r = fma(z, invc, -1.0);
   const double t1 = fma(kd, SA_POW_LN2HI, logc);
   const double t2 = t1 + r;
@@ -112,7 +115,16 @@ SA_HD double sa_pow(double x, double y) {
   const double tl = hi - yl + lo;
   const double ehi = y * yl;
   const double elo = fma(y, tl, fma(y, yl, -ehi));
-  return sa_exp_core(ehi, elo, false);
+  return sa_exp_core(ehi, elo, false, exptab);
+}
+SA_HD double sa_pow(double x, double y) { return sa_pow_t(x, y, kPowLogTab, kExpTab); }
+
+constexpr int kLibmLdsDoubles = 128 * 3 + 256;   // log table + exp table staged in LDS
+// stage both tables into LDS (or any buffer); lane l of nl
+SA_HD void sa_stage_tables(double *dst, int l, int nl) {
+  for (int i = l; i < 128 * 3; i += nl) dst[i] = kPowLogTab[i];
+  unsigned long long *e = reinterpret_cast<unsigned long long *>(dst + 128 * 3);
+  for (int i = l; i < 256; i += nl) e[i] = kExpTab[i];
 }
 
 }  // namespace sacamd

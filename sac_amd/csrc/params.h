@@ -41,7 +41,7 @@ struct WorkItem {
   int slot;           // predictor slot 0/1
   int start, n;       // window [start, start+n) inside the frame
   int lms_class;      // 0/1/2 register-capacity class of the cascade kernel
-  int ols_class;      // 0: n<=32, 1: n<=64, 2: n<=128
+  int ols_class;      // 0: n<=16, 1: n<=32, 2: n<=64, 3: n<=96
   long long off_p;    // doubles: p_lpc / p_lpc+p_lms stream [n]
   long long off_err;  // int32 residual [n]
   long long off_tab;  // doubles: per stage {mutab[vn], powtab[vn]}, stages back to back

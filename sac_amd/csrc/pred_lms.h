@@ -56,11 +56,12 @@ struct LmsLds {
   double *pv;                // stage predictions p[0..4]
   double *exwm;              // expert weights mirror [2][5]
   double *cst;               // vmu[4], sum_powtab[4]
+  double *libm;              // staged log/exp tables of libm_port.h
   int *sv;
   SA_HD static size_t bytes() {
     size_t d = 0;
     for (int s = 0; s < 4; s++) d += (size_t)C::slots(s) * NL + 1;
-    d += 2 * (NL / 64) * 8 + 8 + 2 * kLmsChunk + 3 * kRlsMax + 8 + 10 + 8;
+    d += 2 * (NL / 64) * 8 + 8 + 2 * kLmsChunk + 3 * kRlsMax + 8 + 10 + 8 + kLibmLdsDoubles;
     return d * sizeof(double) + kLmsChunk * sizeof(int) + 16;
   }
   SA_HD void carve(char *base) {
@@ -71,6 +72,7 @@ struct LmsLds {
     pin = d; d += kLmsChunk; pout = d; d += kLmsChunk;
     rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
     pv = d; d += 8; exwm = d; d += 10; cst = d; d += 8;
+    libm = d; d += kLibmLdsDoubles;
     sv = reinterpret_cast<int *>(d);
   }
 };
@@ -112,6 +114,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       for (int i = l; i < cap[s]; i += NL) L.ring[s][i] = 0.0;
     }
     if (l < 8) { L.bc[l] = 0.0; L.pv[l] = 0.0; }
+    sa_stage_tables(L.libm, l, NL);
 #pragma unroll
     for (int s = 0; s < 4; s++) if (l == s) { L.cst[s] = p.vmu[s]; L.cst[4 + s] = sum_powtab[s]; }
     if (l < 10) L.exwm[l] = 1.0 / 5;
@@ -120,6 +123,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     for (int j = 0; j < kRlsMax; j++) Prow[l].v[j] = (j == l) ? 1.0 : 0.0;
   });
   ex.sync();
+  const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
   // uniform mixer state (wave 0)
   double smw[2] = {0.5, 0.5}, smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0;
 
@@ -226,7 +230,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         const double err2 = rerr * rerr;
         const double R = fmax(S0 - S1, 1e-5);
         const double nis = err2 / (phi + R);
-        const double mm = sa_exp(-p.lm_alpha * nis);
+        const double mm = sa_exp_t(-p.lm_alpha * nis, exptab);
         const double alpha = fma(0.999 - 0.99, mm, 0.99);
         denom = 1. / (alpha + phi);
         inv_alpha = 1.0 / alpha;
@@ -240,7 +244,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           zm[e] = 1.0 * smrs[e];
         }
         const double maxz = fmax(zm[0], zm[1]);
-        const double w0 = sa_exp(zm[0] - maxz), w1 = sa_exp(zm[1] - maxz);
+        const double w0 = sa_exp_t(zm[0] - maxz, exptab), w1 = sa_exp_t(zm[1] - maxz, exptab);
         const double inv = 1.0 / (w0 + w1);
         smw[0] = w0 * inv; smw[1] = w1 * inv;
       });

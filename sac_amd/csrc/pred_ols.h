@@ -187,15 +187,16 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
 //    (the scaled column goes to a second triangle, Lk), leaving one barrier per column;
 //  * the element loops issue their LDS loads four elements at a time.
 struct OlsLdsFast {
-  double *X, *Wv, *M, *Wk, *Lk;
+  double *X, *Wv, *M, *Wk, *libm;
   unsigned short *tab;
   SA_HD static size_t bytes(int nmax) {
-    return (size_t)(2 * nmax + 3 * tri_count(nmax)) * sizeof(double) + (size_t)(tri_count(nmax) + 8) * 2 + 16;
+    return (size_t)(2 * nmax + 2 * tri_count(nmax) + kLibmLdsDoubles) * sizeof(double) + (size_t)(tri_count(nmax) + 8) * 2 + 16;
   }
   SA_HD void carve(char *base, int nmax) {
     double *d = reinterpret_cast<double *>(base);
     X = d; d += nmax; Wv = d; d += nmax;
-    M = d; d += tri_count(nmax); Wk = d; d += tri_count(nmax); Lk = d; d += tri_count(nmax);
+    M = d; d += tri_count(nmax); Wk = d; d += tri_count(nmax);
+    libm = d; d += kLibmLdsDoubles;
     tab = reinterpret_cast<unsigned short *>(d);
   }
 };
@@ -209,18 +210,20 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
   const int ntri = tri_count(no);
   OlsLdsFast L;
   L.carve(lds_base, nmax);
+  const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
 
-  typename E::template Reg<double> breg, wreg, sreg, zreg, areg, dreg, invd_mine;
+  typename E::template Reg<double> breg, wreg, sreg, zreg, areg, dreg, invd_mine, acc;
   typename E::template Reg<int> xnext;
 
   ex.par([&](int l) {
-    breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; dreg[l] = 0.0; invd_mine[l] = 0.0;
+    breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; dreg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0;
     if (l < no) { L.X[l] = 0.0; L.Wv[l] = 0.0; }
-    for (int e = l; e < ntri; e += NL) { L.M[e] = 0.0; L.Wk[e] = 0.0; L.Lk[e] = 0.0; }
+    for (int e = l; e < ntri; e += NL) { L.M[e] = 0.0; L.Wk[e] = 0.0; }
     for (int j = l; j < no; j += NL) {
       const int o = tri_off(no, j);
       for (int i = j; i < no; i++) L.tab[o + (i - j)] = (unsigned short)((i << 8) | j);
     }
+    sa_stage_tables(L.libm, l, NL);
     xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
   });
   ex.sync();
@@ -242,7 +245,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       val = (double)self[t];
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
-      const double c = sa_pow(esum + p.beta_add, -p.beta_pow);
+      const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
       ff = one_m_lambda * c;
     });
     ex.par([&](int l) { if (l == 0) p_out[t] = pred; });
@@ -276,17 +279,19 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       km = 0;
       ex.sync();
       bool ok = true;
+      double invd_prev = 0.0;
       for (int kk = 0; kk < no; kk++) {
         const int ok0 = tri_off(no, kk);
         const double dk = ex.lane_bcast(dreg, 0);
         if (dk < 1e-12) { ok = false; break; }
         const double invd = 1.0 / dk;
         const int e0 = tri_off(no, kk + 1);
+        const int okp = kk > 0 ? tri_off(no, kk - 1) : 0;
         ex.par([&](int l) {
           if (l == kk) invd_mine[l] = invd;
-          // scaled column kk -> Lk (rows kk+1..no-1)
-          for (int i = kk + 1 + l; i < no; i += NL) L.Lk[ok0 + (i - kk)] = L.Wk[ok0 + (i - kk)] * invd;
-          // trailing update of every element (i,j), j > kk
+          // column kk-1 is final and no longer read unscaled: store L = W * invd over it
+          if (kk > 0) for (int i = kk + l; i < no; i += NL) L.Wk[okp + (i - (kk - 1))] = L.Wk[okp + (i - (kk - 1))] * invd_prev;
+          // trailing update of every element (i,j), j > kk, from the unscaled column kk
           for (int eb = e0 + l; eb < ntri; eb += 4 * NL) {
             int ij[4]; double li[4], lj[4], w[4];
 #pragma unroll
@@ -310,9 +315,11 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
             }
           }
         });
+        invd_prev = invd;
         ex.sync();
       }
       if (ok) {
+        // (the last column has no rows below the diagonal, nothing left to scale)
         // forward solve: column sweep with register broadcasts
         ex.par([&](int l) { sreg[l] = breg[l]; });
         for (int kk = 0; kk + 1 < no; kk++) {
@@ -320,18 +327,26 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
           const int ok0 = tri_off(no, kk);
           ex.par([&](int l) {
             if (l > kk && l < no) {
-              const double lv = L.Lk[ok0 + (l - kk)];
+              const double lv = L.Wk[ok0 + (l - kk)];
               sreg[l] = fold_fused(kk, l) ? fma(-lv, yk, sreg[l]) : sreg[l] - lv * yk;
             }
           });
         }
         ex.par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
-        // backward solve: strictly serial fused chains, operands broadcast from registers
+        // backward solve: row i is the fused chain z_i - L[i+1][i] w[i+1] - ... in that order
+        // (math.h:67-72).  The accumulator walks up the lanes (wave_shr:1): after step t lane i+t
+        // holds the partial chain, lane no-1 ends with the result.
         for (int i = no - 1; i >= 0; --i) {
           const int oi = tri_off(no, i);
-          ex.par([&](int l) { if (l > i && l < no) areg[l] = -L.Lk[oi + (l - i)]; });
-          double s = ex.lane_bcast(zreg, i);
-          for (int kk = i + 1; kk < no; ++kk) s = fma(ex.lane_bcast(areg, kk), ex.lane_bcast(wreg, kk), s);
+          ex.par([&](int l) {
+            areg[l] = (l > i && l < no) ? -L.Wk[oi + (l - i)] : 0.0;
+            acc[l] = zreg[l];
+          });
+          for (int st = i + 1; st < no; ++st) {
+            ex.shift_up1(acc);
+            ex.par([&](int l) { acc[l] = fma(areg[l], wreg[l], acc[l]); });
+          }
+          const double s = ex.lane_bcast(acc, no - 1 > i ? no - 1 : i);
           ex.par([&](int l) { if (l == i) wreg[l] = s; });
         }
         ex.par([&](int l) { if (l < no) L.Wv[l] = wreg[l]; });

@@ -43,6 +43,8 @@ struct ExecEmu {
   template <class T> T lane_get(const Reg<T> &r, int k) { return r[k]; }
   double lane_bcast(const Reg<double> &r, int k) { return r[k]; }
   int lane_geti(const Reg<int> &r, int k) { return r[k]; }
+  // every lane takes the value of lane-1 (lane 0 keeps its own): DPP wave_shr:1 on the device
+  void shift_up1(Reg<double> &r) { for (int l = NL - 1; l > 0; l--) r[l] = r[l - 1]; }
   // code only lane 0 executes: run once
   template <class F> void lane0(F &&f) { f(); }
   // per-lane code of wave 0 only; wsync orders LDS traffic inside one wave
@@ -100,6 +102,12 @@ struct ExecDev {
   }
   template <class T> SA_D T lane_get(const Reg<T> &r, int k) { return __shfl(r.v, k, 64); }
   SA_D int lane_geti(const Reg<int> &r, int k) { return __builtin_amdgcn_readlane(r.v, k); }
+  SA_D void shift_up1(Reg<double> &r) {
+    int lo = __double2loint(r.v), hi = __double2hiint(r.v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    r.v = __hiloint2double(hi, lo);
+  }
   template <class F> SA_D void lane0(F &&f) { if (threadIdx.x == 0) f(); }
   template <class F> SA_D void leader_par(F &&f) { if (threadIdx.x < 64) f((int)threadIdx.x); }
   SA_D void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
