@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 64)), help="frames per GPU per step")
     ap.add_argument("--seconds", type=float, default=float(os.environ.get("SAC_BENCH_SECONDS", 20.0)), help="frame length")
     ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SAC_BENCH_GROUPS", 4)),
+                    help="independent frame groups run concurrently on one GPU (own context + HIP streams each)")
     ap.add_argument("--mode", default="high")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="decode every record with the oracle afterwards (slow)")
@@ -138,34 +140,60 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import sac_amd.api as api
+    from concurrent.futures import ThreadPoolExecutor
 
     frames, il, n = make_batch(args.frames, args.seconds, seed0=1000 + 1000 * rank)
     d_pcm = torch.from_numpy(il).to(device)            # interleaved L/R int16, resident in HBM
     torch.cuda.synchronize()
     framesize = int(20 * RATE) if args.seconds >= 20 else n   # reference: max_framelen(20 s) * rate
-    ctx = api.Context(2, max(n, 16), args.frames, device=local_rank)
-    frame_off = np.arange(args.frames, dtype=np.int64) * n
-    nsamp = np.full(args.frames, n, np.int32)
     cfg = api.make_cfg(args.mode, num_threads=args.dds_n, reset=1)
+    # The kernels are latency-bound recurrences (one wave or one workgroup per frame x candidate x
+    # channel); independent groups of frames therefore run concurrently, each with its own context
+    # (own device buffers and HIP streams), so that one group's low-occupancy phases (final pass,
+    # range coder) overlap the others' search generations.
+    ngroups = max(1, min(args.groups, args.frames))
+    bounds = [round(g * args.frames / ngroups) for g in range(ngroups + 1)]
+    groups = []
+    for g in range(ngroups):
+        lo, hi = bounds[g], bounds[g + 1]
+        ctx = api.Context(2, max(n, 16), hi - lo, device=local_rank)
+        groups.append((ctx, np.arange(lo, hi, dtype=np.int64) * n, np.full(hi - lo, n, np.int32)))
+    pool = ThreadPoolExecutor(max_workers=ngroups)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    def run_group(g):
+        ctx, frame_off, nsamp = groups[g]
         ctx.attach_s16_device(d_pcm.data_ptr(), frame_off, nsamp, framesize)
         ctx.analyse(cfg)
-        recs, prof = ctx.encode_frames(cfg)
+        recs, prof = ctx.encode_frames(cfg)      # ctypes releases the GIL: groups overlap on the GPU
+        return recs
+
+    def step():
+        recs = [r for part in pool.map(run_group, range(ngroups)) for r in part]
         if dist is not None:
             allrecs = gather_records(recs, rank, world, device)
         else:
             allrecs = recs
         return recs, allrecs
 
+    def kernel_times():
+        tot = None
+        for ctx, _, _ in groups:
+            kt = ctx.kernel_times(reset=True)
+            if tot is None:
+                tot = kt
+            else:
+                for k in kt:
+                    tot[k]["ms"] += kt[k]["ms"]; tot[k]["launches"] += kt[k]["launches"]
+        return tot
+
     for _ in range(args.warmup):
         step()
-    ctx.kernel_times(reset=True)
+    kernel_times()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -176,7 +204,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    kt = ctx.kernel_times(reset=True)
+    kt = kernel_times()
 
     samples_per_step = args.frames * n * 2 * world
     value = samples_per_step * args.steps / dt / 1e6
@@ -204,6 +232,7 @@ def main():
             "config": {"workload": f"{args.frames} frames/GPU x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
                                    f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
                        "frames_per_gpu": args.frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
+                       "concurrent_groups": ngroups,
                        "parallelism": f"frames sharded over {world} GPU(s), RCCL record gather"},
             "bps": bps, "x_realtime": (args.frames * world * args.seconds * args.steps) / dt,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
