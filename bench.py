@@ -17,6 +17,10 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); every context here
+# uses 5 streams (main + one per kernel class) and several contexts may run concurrently.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import sys
 import time
 

@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")   # must be set before the HIP runtime initialises
 from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_longlong, c_void_p
 
 import numpy as np

@@ -114,6 +114,9 @@ struct sacamd_ctx {
   DevBuf<unsigned char> d_cstate, d_cout;
   DevBuf<int> d_clen;
   DevBuf<CoderJob> d_jobs;
+  DevBuf<RemapJob> d_rj;
+  DevBuf<int> d_prefix, d_tmp_s2u, d_tmp_mb;
+  DevBuf<long long> d_out3;
   bool coder_tables = false;
   struct EncOut { std::vector<unsigned char> bytes; int mapped = 0, maxbpn = 0; };
   std::vector<EncOut> enc;   // [frame*nch+ch]
@@ -326,6 +329,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();
+  c->d_rj.release(); c->d_prefix.release(); c->d_tmp_s2u.release(); c->d_tmp_mb.release(); c->d_out3.release();
   delete c;
 }
 
