@@ -36,7 +36,7 @@ struct CoderModel {
 
 // read-only tables staged in LDS
 struct CoderTabs {
-  short fwd[kPScale];          // LogDomain::Fwd
+  short fwdh[kPScale / 2 + 1]; // LogDomain::Fwd for p <= 16384; Fwd(p) = -Fwd(32768-p) above (odd symmetry)
   unsigned pinv[4097];         // x in [-2048,2048] -> p = clamp(Inv(x)) | Fwd(p) << 16
   unsigned short divt[304];    // PSCALE / (cnt + 3)   (counter.h:40-51)
 };
@@ -131,12 +131,14 @@ template <int N> SA_HD int sse_interp(int pl, int ph, int pmod) {
   return clampi((pl * (xscale - pmod) + ph * pmod) / xscale, 1, kPScaleM);
 }
 
+SA_HD int fwd_at(const CoderTabs &T, int p) { return p <= kPScale / 2 ? (int)T.fwdh[p] : -(int)T.fwdh[kPScale - p]; }
+
 SA_HD void coder_tabs_init(CoderTabs &T, const short *g_fwd, const unsigned short *g_inv, int lane, int nl) {
-  for (int i = lane; i < kPScale; i += nl) T.fwd[i] = g_fwd[i];
+  for (int i = lane; i <= kPScale / 2; i += nl) T.fwdh[i] = g_fwd[i];
   for (int i = lane; i < 4097; i += nl) {
     const int x = i - 2048;
     const int p = x < -2047 ? 1 : (x > 2047 ? kPScaleM : clampi((int)g_inv[x + 2047], 1, kPScaleM));
-    T.pinv[i] = (unsigned)p | ((unsigned)(unsigned short)g_fwd[p] << 16);
+    T.pinv[i] = (unsigned)p | ((unsigned)(unsigned short)g_fwd[p] << 16);   // full-range source table
   }
   for (int i = lane; i < 304; i += nl) T.divt[i] = (unsigned short)(kPScale / (i + 3));
 }
@@ -221,7 +223,7 @@ SA_HD CoderDescR coder_describe(const CoderWin &W, const CoderTabs &T, int i, in
   D.a = pest | (i1 << 16);
   D.b = i2 | (i3 << 16);
   D.c = i4 | (mix << 16) | (s1 << 24);
-  D.d = s2 | (type << 8) | (bit << 9) | ((int)(unsigned short)T.fwd[pest] << 16);
+  D.d = s2 | (type << 8) | (bit << 9) | ((int)(unsigned short)fwd_at(T, pest) << 16);
   return D;
 }
 
@@ -245,14 +247,14 @@ SA_HD void coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, 
     const int *wp = M.lmixref[mixc];
 #pragma unroll
     for (int q = 0; q < 5; q++) w[q] = wp[q];
-    st[0] = st_pest; st[1] = T.fwd[pl.p1]; st[2] = T.fwd[c1.p1]; st[3] = T.fwd[c2.p1]; st[4] = T.fwd[c3.p1];
+    st[0] = st_pest; st[1] = fwd_at(T, pl.p1); st[2] = fwd_at(T, c1.p1); st[3] = fwd_at(T, c2.p1); st[4] = fwd_at(T, c3.p1);
     x = mix_dot<5>(w, st);
   } else {
     c1 = c1sig; c2 = M.csig1[i2];
     const int *wp = M.lmixsig[mixc];
 #pragma unroll
     for (int q = 0; q < 3; q++) w[q] = wp[q];
-    st[0] = T.fwd[pl.p1]; st[1] = T.fwd[c1.p1]; st[2] = T.fwd[c2.p1]; st[3] = 0; st[4] = 0;
+    st[0] = fwd_at(T, pl.p1); st[1] = fwd_at(T, c1.p1); st[2] = fwd_at(T, c2.p1); st[3] = 0; st[4] = 0;
     x = mix_dot<3>(w, st);
   }
   const unsigned pk = pinv_lookup(T.pinv, x);
@@ -261,10 +263,10 @@ SA_HD void coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, 
   sse_bin<15>(sp1, &q1, &r1);
   const int m1a = m1[q1], m1b = m1[q1 + 1];
   const int pr1 = sse_interp<15>(m1a, m1b, r1);
-  sse_bin<15>(T.fwd[pr1], &q2, &r2);
+  sse_bin<15>(fwd_at(T, pr1), &q2, &r2);
   const int m2a = m2[q2], m2b = m2[q2 + 1];
   const int pr2 = sse_interp<15>(m2a, m2b, r2);
-  int sf[2] = {T.fwd[(pr1 + pr2 + 1) >> 1], sp1};
+  int sf[2] = {fwd_at(T, (pr1 + pr2 + 1) >> 1), sp1};
   const int p = (int)(pinv_lookup(T.pinv, mix_dot<2>(sw, sf)) & 0xffff);
   rc.encode((unsigned)p, bit);
   // ---- updates (computed from the loaded values; stores only)
@@ -304,7 +306,8 @@ SA_HD void map_model_init(MapModel &m, const unsigned *pinv) {
   m.finalmix[0] = m.finalmix[1] = 0; m.lb = 0;
   for (int i = 0; i <= 32; i++) { const int x = squash(pinv, i * 171 - 2662); m.sse[0][i] = (unsigned short)x; m.sse[1][i] = (unsigned short)x; }   // SSENL<32>: xscale 171
 }
-SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char *uh, const short *fwd, const unsigned *pinv, RangeEnc &rc) {
+SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char *uh, const CoderTabs &T, RangeEnc &rc) {
+  const unsigned *pinv = T.pinv;
   for (int i = 1; i <= 1 << 15; i++) {
     for (int hi = 0; hi < 2; hi++) {
       const unsigned char *a = hi ? uh : ul;
@@ -319,14 +322,14 @@ SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char 
       if (i > 3) sctx += (a[i - 4] << 3);
       unsigned short *px = &m.cctx[(hi ? 32 : 0) + sctx];
       int *w = hi ? m.mixh[ctx1 + (ctx3 << 1)] : m.mixl[ctx1 + (ctx3 << 1)];
-      int st[5] = {fwd[*pc1], fwd[*pc2], fwd[*pc3], fwd[*pc4], fwd[*px]};
+      int st[5] = {fwd_at(T, *pc1), fwd_at(T, *pc2), fwd_at(T, *pc3), fwd_at(T, *pc4), fwd_at(T, *px)};
       const unsigned pk = pinv_lookup(pinv, mix_dot<5>(w, st));
       const int p1 = (int)(pk & 0xffff), sp1 = (short)(pk >> 16);
       int q, r;
       unsigned short *mp = m.sse[m.lb];
       sse_bin<32>(sp1, &q, &r);
       const int ps = sse_interp<32>(mp[q], mp[q + 1], r);
-      int sf[2] = {fwd[ps], sp1};
+      int sf[2] = {fwd_at(T, ps), sp1};
       const int p = (int)(pinv_lookup(pinv, mix_dot<2>(m.finalmix, sf)) & 0xffff);
       const int bit = a[i];
       rc.encode((unsigned)p, bit);
@@ -357,7 +360,7 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
   rc.init(out, cap);
   if (used) {
     ex.par([&](int l) {
-      if (l == 0) { map_model_init(MM, T.pinv); map_encode(MM, used, used + 32769, T.fwd, T.pinv, rc); }
+      if (l == 0) { map_model_init(MM, T.pinv); map_encode(MM, used, used + 32769, T, rc); }
     });
     ex.sync();
   }
