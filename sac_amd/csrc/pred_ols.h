@@ -187,20 +187,24 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
 //    (the scaled column goes to a second triangle, Lk), leaving one barrier per column;
 //  * the element loops issue their LDS loads four elements at a time.
 struct OlsLdsFast {
-  double *X, *Wv, *M, *Wk, *libm;
-  unsigned short *tab;
+  double *X, *Wv, *Dv, *M, *Lk, *libm;
   SA_HD static size_t bytes(int nmax) {
-    return (size_t)(2 * nmax + 2 * tri_count(nmax) + kLibmLdsDoubles) * sizeof(double) + (size_t)(tri_count(nmax) + 8) * 2 + 16;
+    return (size_t)(3 * nmax + 2 * tri_count(nmax) + kLibmLdsDoubles) * sizeof(double) + 16;
   }
   SA_HD void carve(char *base, int nmax) {
     double *d = reinterpret_cast<double *>(base);
-    X = d; d += nmax; Wv = d; d += nmax;
-    M = d; d += tri_count(nmax); Wk = d; d += tri_count(nmax);
+    X = d; d += nmax; Wv = d; d += nmax; Dv = d; d += nmax;
+    M = d; d += tri_count(nmax); Lk = d; d += tri_count(nmax);
     libm = d; d += kLibmLdsDoubles;
-    tab = reinterpret_cast<unsigned short *>(d);
   }
 };
 
+// One wave, lane l <-> row l of the covariance / L (n_ols <= 64).  The factorisation is the
+// reference's own left-looking loop nest (math.h:21-73): column j's chains for all rows i >= j run
+// in parallel across lanes, each lane walking k = 0..j-1 in order with its own L[i][k] (one
+// coalesced LDS read per k: column k is contiguous in the packed triangle) and row j's L[j][k]
+// (same-address broadcast read).  The reciprocal of pivot j-1 is issued before column j's first
+// j-1 terms, which do not need it, and consumed for the last term.
 template <class E>
 SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int *other, int n,
                           double *p_out, char *lds_base, int nmax) {
@@ -212,17 +216,13 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
   L.carve(lds_base, nmax);
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
 
-  typename E::template Reg<double> breg, wreg, sreg, zreg, areg, dreg, invd_mine, acc;
+  typename E::template Reg<double> xr, breg, wreg, sreg, zreg, areg, invd_mine, acc, accprev;
   typename E::template Reg<int> xnext;
 
   ex.par([&](int l) {
-    breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; dreg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0;
-    if (l < no) { L.X[l] = 0.0; L.Wv[l] = 0.0; }
-    for (int e = l; e < ntri; e += NL) { L.M[e] = 0.0; L.Wk[e] = 0.0; }
-    for (int j = l; j < no; j += NL) {
-      const int o = tri_off(no, j);
-      for (int i = j; i < no; i++) L.tab[o + (i - j)] = (unsigned short)((i << 8) | j);
-    }
+    xr[l] = 0.0; breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0; accprev[l] = 0.0;
+    if (l < no) { L.X[l] = 0.0; L.Wv[l] = 0.0; L.Dv[l] = 0.0; }
+    for (int e = l; e < ntri; e += NL) { L.M[e] = 0.0; L.Lk[e] = 0.0; }
     sa_stage_tables(L.libm, l, NL);
     xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
   });
@@ -235,7 +235,8 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
 
   for (int t = 0; t < n; t++) {
     ex.par([&](int l) {
-      if (l < no) L.X[l] = (double)xnext[l];
+      xr[l] = (double)xnext[l];
+      if (l < no) L.X[l] = xr[l];
       if (l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
     });
     ex.sync();
@@ -249,85 +250,98 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       ff = one_m_lambda * c;
     });
     ex.par([&](int l) { if (l == 0) p_out[t] = pred; });
-    km++;
-    const bool solve = km >= p.k;
-    // covariance / rhs update; when a solve follows, also seed the LDL^T workspace
+    // covariance / rhs update (ols.cpp:38-45): lane = row i, loop over columns j <= i
     ex.par([&](int l) {
-      for (int e0 = l; e0 < ntri; e0 += 4 * NL) {
-        int ij[4]; double m[4], xr[4], xc[4];
+      if (l < no) {
+        const double xi = xr[l];
+        int j = 0;
+        for (; j + 4 <= no; j += 4) {
+          double m[4], xj[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int e = e0 + u * NL; ij[u] = e < ntri ? L.tab[e] : 0; }
+          for (int u = 0; u < 4; u++) { xj[u] = L.X[j + u]; m[u] = (l >= j + u) ? L.M[tri_off(no, j + u) + (l - (j + u))] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int e = e0 + u * NL; m[u] = e < ntri ? L.M[e] : 0.0; xr[u] = L.X[ij[u] >> 8]; xc[u] = L.X[ij[u] & 255]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int e = e0 + u * NL;
-          if (e < ntri) {
-            const double v = fma(lambda, m[u], ff * (xr[u] * xc[u]));
-            L.M[e] = v;
-            if (solve) {
-              const double w = ((ij[u] >> 8) == (ij[u] & 255)) ? v + nu : v;
-              L.Wk[e] = w;
-              if (e == 0) dreg[l] = w;
-            }
-          }
+          for (int u = 0; u < 4; u++) if (l >= j + u) L.M[tri_off(no, j + u) + (l - (j + u))] = fma(lambda, m[u], ff * (xi * xj[u]));
         }
+        for (; j < no; j++) if (l >= j) { const int e = tri_off(no, j) + (l - j); L.M[e] = fma(lambda, L.M[e], ff * (xi * L.X[j])); }
+        breg[l] = fma(lambda, breg[l], ff * (xi * val));
       }
-      if (l < no) breg[l] = fma(lambda, breg[l], ff * (L.X[l] * val));
     });
-    if (solve) {
+    km++;
+    if (km >= p.k) {
       km = 0;
-      ex.sync();
+      // ---- LDL^T, left-looking.  Each lane only re-reads M elements it wrote itself.
       bool ok = true;
-      double invd_prev = 0.0;
-      for (int kk = 0; kk < no; kk++) {
-        const int ok0 = tri_off(no, kk);
-        const double dk = ex.lane_bcast(dreg, 0);
-        if (dk < 1e-12) { ok = false; break; }
-        const double invd = 1.0 / dk;
-        const int e0 = tri_off(no, kk + 1);
-        const int okp = kk > 0 ? tri_off(no, kk - 1) : 0;
+      double dprev = 0.0, invd_prev = 0.0;
+      for (int j = 0; j < no; j++) {
+        const int oj = tri_off(no, j);
         ex.par([&](int l) {
-          if (l == kk) invd_mine[l] = invd;
-          // column kk-1 is final and no longer read unscaled: store L = W * invd over it
-          if (kk > 0) for (int i = kk + l; i < no; i += NL) L.Wk[okp + (i - (kk - 1))] = L.Wk[okp + (i - (kk - 1))] * invd_prev;
-          // trailing update of every element (i,j), j > kk, from the unscaled column kk
-          for (int eb = e0 + l; eb < ntri; eb += 4 * NL) {
-            int ij[4]; double li[4], lj[4], w[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int e = eb + u * NL; ij[u] = e < ntri ? L.tab[e] : ((kk + 1) << 8 | (kk + 1)); }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int e = eb + u * NL;
-              li[u] = L.Wk[ok0 + ((ij[u] >> 8) - kk)]; lj[u] = L.Wk[ok0 + ((ij[u] & 255) - kk)];
-              w[u] = e < ntri ? L.Wk[e] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int e = eb + u * NL;
-              if (e < ntri) {
-                const int j = ij[u] & 255;
-                const double tt = (li[u] * invd) * (lj[u] * invd);
-                const double r = fold_fused(kk, j) ? fma(-tt, dk, w[u]) : w[u] - tt * dk;
-                L.Wk[e] = r;
-                if (e == e0) dreg[l] = r;      // next pivot: lane 0, first element
-              }
-            }
-          }
+          double a_ = (l >= j && l < no) ? L.M[oj + (l - j)] : 0.0;
+          if (l == j) a_ = a_ + nu;
+          acc[l] = a_;
         });
-        invd_prev = invd;
+        // terms k = 0 .. j-2: columns already stored (scaled) in Lk
+        int k = 0;
+        for (; k + 4 <= j - 1; k += 4) {
+          ex.par([&](int l) {
+            if (l >= j && l < no) {
+              double a[4], b[4], d[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) { const int ok_ = tri_off(no, k + u); a[u] = L.Lk[ok_ + (l - (k + u))]; b[u] = L.Lk[ok_ + (j - (k + u))]; d[u] = L.Dv[k + u]; }
+              double s = acc[l];
+#pragma unroll
+              for (int u = 0; u < 4; u++) { const double tt = a[u] * b[u]; s = s - tt * d[u]; }   // k <= j-2: never the fused term
+              acc[l] = s;
+            }
+          });
+        }
+        for (; k < j - 1; k++) {
+          ex.par([&](int l) {
+            if (l >= j && l < no) {
+              const int ok_ = tri_off(no, k);
+              const double tt = L.Lk[ok_ + (l - k)] * L.Lk[ok_ + (j - k)];
+              acc[l] = acc[l] - tt * L.Dv[k];
+            }
+          });
+        }
+        if (j > 0) {
+          // finish column j-1: L[i][j-1] = lij * invD (math.h:49), keep it for the last term
+          const int op = tri_off(no, j - 1);
+          ex.par([&](int l) {
+            const double lp = accprev[l] * invd_prev;
+            accprev[l] = lp;
+            if (l > j - 1 && l < no) L.Lk[op + (l - (j - 1))] = lp;
+          });
+          const double bj = ex.lane_bcast(accprev, j);
+          const bool fz = fold_fused(j - 1, j);
+          ex.par([&](int l) {
+            if (l >= j && l < no) {
+              const double tt = accprev[l] * bj;
+              acc[l] = fz ? fma(-tt, dprev, acc[l]) : acc[l] - tt * dprev;
+            }
+          });
+        }
+        const double dj = ex.lane_bcast(acc, j);
+        if (dj < 1e-12) { ok = false; break; }
+        const double invd = 1.0 / dj;
+        ex.par([&](int l) {
+          if (l == j) invd_mine[l] = invd;
+          if (l == 0) L.Dv[j] = dj;
+          accprev[l] = acc[l];
+        });
+        dprev = dj; invd_prev = invd;
         ex.sync();
       }
       if (ok) {
-        // (the last column has no rows below the diagonal, nothing left to scale)
         // forward solve: column sweep with register broadcasts
         ex.par([&](int l) { sreg[l] = breg[l]; });
         for (int kk = 0; kk + 1 < no; kk++) {
           const double yk = ex.lane_bcast(sreg, kk);
           const int ok0 = tri_off(no, kk);
+          const bool anyf = (kk + 1 < no);
+          (void)anyf;
           ex.par([&](int l) {
             if (l > kk && l < no) {
-              const double lv = L.Wk[ok0 + (l - kk)];
+              const double lv = L.Lk[ok0 + (l - kk)];
               sreg[l] = fold_fused(kk, l) ? fma(-lv, yk, sreg[l]) : sreg[l] - lv * yk;
             }
           });
@@ -339,14 +353,14 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         for (int i = no - 1; i >= 0; --i) {
           const int oi = tri_off(no, i);
           ex.par([&](int l) {
-            areg[l] = (l > i && l < no) ? -L.Wk[oi + (l - i)] : 0.0;
+            areg[l] = (l > i && l < no) ? -L.Lk[oi + (l - i)] : 0.0;
             acc[l] = zreg[l];
           });
           for (int st = i + 1; st < no; ++st) {
             ex.shift_up1(acc);
             ex.par([&](int l) { acc[l] = fma(areg[l], wreg[l], acc[l]); });
           }
-          const double s = ex.lane_bcast(acc, no - 1 > i ? no - 1 : i);
+          const double s = ex.lane_bcast(acc, no - 1);
           ex.par([&](int l) { if (l == i) wreg[l] = s; });
         }
         ex.par([&](int l) { if (l < no) L.Wv[l] = wreg[l]; });
