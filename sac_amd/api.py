@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "sacamd_frames_attach_s16_device", "sacamd_analyse", "sacamd_get_stats", "sacamd_evaluate",
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
-    "sacamd_kernel_times", "sacamd_abi_version",
+    "sacamd_kernel_times", "sacamd_debug_ols_profile", "sacamd_abi_version",
 ]
 
 
@@ -213,6 +213,11 @@ class Context:
         c = c_double(0)
         self._chk(self.lib.sacamd_debug_cost(self.h, kind, _vp(e), e.size, byref(c)))
         return c.value
+
+    def ols_profile(self, on=True):
+        out = np.zeros(8, np.uint64)
+        self._chk(self.lib.sacamd_debug_ols_profile(self.h, int(on), _vp(out)))
+        return out
 
     def kernel_times(self, reset=True):
         out = np.zeros(16)

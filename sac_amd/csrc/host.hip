@@ -85,6 +85,7 @@ struct sacamd_ctx {
   hipStream_t cls_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // concurrent kernel classes
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::string err;
+  unsigned long long *d_prof = nullptr;   // debug: OLS section counters
   // staged batch
   int nframes = 0, framesize = 0;
   bool analysed = false, final_done = false, encoded = false;
@@ -164,7 +165,7 @@ int sync_stream(sacamd_ctx *c) {
   return 0;
 }
 
-PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride}; }
+PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride, c->d_prof}; }
 
 // ------------------------------------------------------------ work-item construction
 struct Cand { int frame; const float *coefs; int start, n; bool optimize; int optk; };
@@ -589,6 +590,16 @@ API int sacamd_debug_cost(sacamd_ctx *c, int kind, const int32_t *err, int n, do
   int r = run_costs(c, kind, off, nn, c->d_err.p, out);
   if (r) return r;
   *cost = out[0];
+  return 0;
+}
+
+// debug: enable (on!=0) / read the OLS kernel's section cycle counters of the last launch
+API int sacamd_debug_ols_profile(sacamd_ctx *c, int on, unsigned long long *out8) {
+  if (!c) return SACAMD_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (on && !c->d_prof) { HIPCHK(c, hipMalloc((void **)&c->d_prof, 64)); HIPCHK(c, hipMemset(c->d_prof, 0, 64)); }
+  if (out8 && c->d_prof) HIPCHK(c, hipMemcpy(out8, c->d_prof, 64, hipMemcpyDeviceToHost));
+  if (!on && c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
   return 0;
 }
 

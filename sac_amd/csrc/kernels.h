@@ -9,6 +9,7 @@ namespace sacamd {
 struct PcmView {            // centred planar int32 PCM of the staged batch
   const int *pcm;
   long long frame_stride, ch_stride;
+  unsigned long long *prof;   // optional: 8 section cycle counters of the OLS kernel (debug)
 };
 
 // ---- analyse (kernels_misc.hip)

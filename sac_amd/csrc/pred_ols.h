@@ -207,8 +207,10 @@ struct OlsLdsFast {
 // j-1 terms, which do not need it, and consumed for the last term.
 template <class E>
 SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                          double *p_out, char *lds_base, int nmax) {
+                          double *p_out, char *lds_base, int nmax, unsigned long long *prof = nullptr) {
   static_assert(E::nl == 64, "one-wave path");
+  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
+#define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
   constexpr int NL = 64;
   const int no = p.n_ols;
   const int ntri = tri_count(no);
@@ -233,6 +235,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
   const double lambda = p.lambda, nu = p.nu_eff;
   const double one_m_lambda = 1.0 - lambda;
 
+  if (prof) tc = E::clock();
   for (int t = 0; t < n; t++) {
     ex.par([&](int l) {
       xr[l] = (double)xnext[l];
@@ -250,22 +253,26 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       ff = one_m_lambda * c;
     });
     ex.par([&](int l) { if (l == 0) p_out[t] = pred; });
+    SA_TICK(0);
     // covariance / rhs update (ols.cpp:38-45): lane = row i, loop over columns j <= i
     ex.par([&](int l) {
       if (l < no) {
         const double xi = xr[l];
         int j = 0;
-        for (; j + 4 <= no; j += 4) {
-          double m[4], xj[4];
+        // loads are unconditional (rows above the diagonal read harmless neighbours of the packed
+        // triangle), only the stores are masked
+        for (; j + 8 <= no; j += 8) {
+          double m[8], xj[8];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { xj[u] = L.X[j + u]; m[u] = (l >= j + u) ? L.M[tri_off(no, j + u) + (l - (j + u))] : 0.0; }
+          for (int u = 0; u < 8; u++) { xj[u] = L.X[j + u]; m[u] = L.M[tri_off(no, j + u) + (l - (j + u))]; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) if (l >= j + u) L.M[tri_off(no, j + u) + (l - (j + u))] = fma(lambda, m[u], ff * (xi * xj[u]));
+          for (int u = 0; u < 8; u++) { const double v = fma(lambda, m[u], ff * (xi * xj[u])); if (l >= j + u) L.M[tri_off(no, j + u) + (l - (j + u))] = v; }
         }
-        for (; j < no; j++) if (l >= j) { const int e = tri_off(no, j) + (l - j); L.M[e] = fma(lambda, L.M[e], ff * (xi * L.X[j])); }
+        for (; j < no; j++) { const int e = tri_off(no, j) + (l - j); const double v = fma(lambda, L.M[e], ff * (xi * L.X[j])); if (l >= j) L.M[e] = v; }
         breg[l] = fma(lambda, breg[l], ff * (xi * val));
       }
     });
+    SA_TICK(1);
     km++;
     if (km >= p.k) {
       km = 0;
@@ -281,26 +288,29 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         });
         // terms k = 0 .. j-2: columns already stored (scaled) in Lk
         int k = 0;
-        for (; k + 4 <= j - 1; k += 4) {
+        for (; k + 8 <= j - 1; k += 8) {
           ex.par([&](int l) {
-            if (l >= j && l < no) {
-              double a[4], b[4], d[4];
+            double a[8], b[8], d[8];
 #pragma unroll
-              for (int u = 0; u < 4; u++) { const int ok_ = tri_off(no, k + u); a[u] = L.Lk[ok_ + (l - (k + u))]; b[u] = L.Lk[ok_ + (j - (k + u))]; d[u] = L.Dv[k + u]; }
-              double s = acc[l];
+            for (int u = 0; u < 8; u++) { const int ok_ = tri_off(no, k + u); a[u] = L.Lk[ok_ + (l - (k + u))]; b[u] = L.Lk[ok_ + (j - (k + u))]; d[u] = L.Dv[k + u]; }
+            double s_ = acc[l];
 #pragma unroll
-              for (int u = 0; u < 4; u++) { const double tt = a[u] * b[u]; s = s - tt * d[u]; }   // k <= j-2: never the fused term
-              acc[l] = s;
-            }
+            for (int u = 0; u < 8; u++) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }   // k <= j-2: never the fused term
+            acc[l] = s_;
           });
         }
-        for (; k < j - 1; k++) {
+        if (k < j - 1) {
           ex.par([&](int l) {
-            if (l >= j && l < no) {
-              const int ok_ = tri_off(no, k);
-              const double tt = L.Lk[ok_ + (l - k)] * L.Lk[ok_ + (j - k)];
-              acc[l] = acc[l] - tt * L.Dv[k];
+            double a[8], b[8], d[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int kk = (k + u < j - 1) ? k + u : k;       // clamp: loads stay in range
+              const int ok_ = tri_off(no, kk); a[u] = L.Lk[ok_ + (l - kk)]; b[u] = L.Lk[ok_ + (j - kk)]; d[u] = L.Dv[kk];
             }
+            double s_ = acc[l];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (k + u < j - 1) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }
+            acc[l] = s_;
           });
         }
         if (j > 0) {
@@ -329,16 +339,15 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
           accprev[l] = acc[l];
         });
         dprev = dj; invd_prev = invd;
-        ex.sync();
+        ex.wsync();   // one wave: LDS traffic is in order, only the compiler needs the fence
       }
+      SA_TICK(2);
       if (ok) {
         // forward solve: column sweep with register broadcasts
         ex.par([&](int l) { sreg[l] = breg[l]; });
         for (int kk = 0; kk + 1 < no; kk++) {
           const double yk = ex.lane_bcast(sreg, kk);
           const int ok0 = tri_off(no, kk);
-          const bool anyf = (kk + 1 < no);
-          (void)anyf;
           ex.par([&](int l) {
             if (l > kk && l < no) {
               const double lv = L.Lk[ok0 + (l - kk)];
@@ -347,27 +356,38 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
           });
         }
         ex.par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
+        SA_TICK(3);
         // backward solve: row i is the fused chain z_i - L[i+1][i] w[i+1] - ... in that order
-        // (math.h:67-72).  The accumulator walks up the lanes (wave_shr:1): after step t lane i+t
-        // holds the partial chain, lane no-1 ends with the result.
+        // (math.h:67-72).  Every lane walks the same chain with same-address (broadcast) LDS
+        // reads issued eight at a time; only the fma sits on the dependency chain.
+        ex.par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS (D is no longer needed)
+        ex.wsync();
         for (int i = no - 1; i >= 0; --i) {
           const int oi = tri_off(no, i);
-          ex.par([&](int l) {
-            areg[l] = (l > i && l < no) ? -L.Lk[oi + (l - i)] : 0.0;
-            acc[l] = zreg[l];
+          double s_ = 0.0;
+          ex.uni([&]() {
+            s_ = L.Dv[i];
+            int kk = i + 1;
+            for (; kk + 8 <= no; kk += 8) {
+              double a[8], w[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) { a[u] = L.Lk[oi + (kk + u - i)]; w[u] = L.Wv[kk + u]; }
+#pragma unroll
+              for (int u = 0; u < 8; u++) s_ = fma(-a[u], w[u], s_);
+            }
+            for (; kk < no; ++kk) s_ = fma(-L.Lk[oi + (kk - i)], L.Wv[kk], s_);
           });
-          for (int st = i + 1; st < no; ++st) {
-            ex.shift_up1(acc);
-            ex.par([&](int l) { acc[l] = fma(areg[l], wreg[l], acc[l]); });
-          }
-          const double s = ex.lane_bcast(acc, no - 1);
-          ex.par([&](int l) { if (l == i) wreg[l] = s; });
+          ex.par([&](int l) { if (l == 0) L.Wv[i] = s_; });
+          ex.wsync();
         }
-        ex.par([&](int l) { if (l < no) L.Wv[l] = wreg[l]; });
+        SA_TICK(4);
       }
     }
     ex.sync();
+    SA_TICK(5);
   }
+  if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[i] = tp[i]; });
+#undef SA_TICK
 }
 
 }  // namespace sacamd

@@ -47,6 +47,7 @@ struct ExecEmu {
   void shift_up1(Reg<double> &r) { for (int l = NL - 1; l > 0; l--) r[l] = r[l - 1]; }
   // code only lane 0 executes: run once
   template <class F> void lane0(F &&f) { f(); }
+  static unsigned long long clock() { return 0; }
   // per-lane code of wave 0 only; wsync orders LDS traffic inside one wave
   template <class F> void leader_par(F &&f) { for (int l = 0; l < (NL < 64 ? NL : 64); l++) f(l); }
   void wsync() {}
@@ -109,6 +110,7 @@ struct ExecDev {
     r.v = __hiloint2double(hi, lo);
   }
   template <class F> SA_D void lane0(F &&f) { if (threadIdx.x == 0) f(); }
+  static SA_D unsigned long long clock() { return __builtin_readcyclecounter(); }
   template <class F> SA_D void leader_par(F &&f) { if (threadIdx.x < 64) f((int)threadIdx.x); }
   SA_D void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
   // value of lane k (k uniform across the wave) -> scalar broadcast via v_readlane_b32

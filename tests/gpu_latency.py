@@ -16,8 +16,11 @@ for nA, nM0, taps in [(8, 0, None), (16, 0, None), (32, 0, None), (32, 16, None)
         g = P[:, 2].copy(); g[24] = nA; g[9] = nM0
         if taps: g[28], g[29], g[30], g[37] = taps
         ctx.kernel_times()
+        ctx.ols_profile(True)
         ctx.debug_predict(0, g, 0, n, opt)
+        prof = ctx.ols_profile(True).astype(float) / n
         kt = ctx.kernel_times()
+        print("     ols cycles/step: predict %.0f cov %.0f factor %.0f fwd %.0f bwd %.0f tail %.0f" % tuple(prof[:6]), flush=True)
         print(f"n_ols {nA+nM0:3d} taps {taps if taps else 'default'} k={4 if opt else 1}: ols {kt['ols']['ms']*1e3/n:8.2f}  lms {kt['lms']['ms']*1e3/n:7.2f}  bias {kt['bias']['ms']*1e3/n:6.2f}", flush=True)
 # coder latency
 rng = np.random.default_rng(0)
