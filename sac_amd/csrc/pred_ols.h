@@ -277,45 +277,49 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
     if (km >= p.k) {
       km = 0;
       // ---- LDL^T, left-looking.  Each lane only re-reads M elements it wrote itself.
+      // Lanes that own no row of the current column run the same arithmetic on harmless values
+      // (no exec-mask churn); only stores are masked.  Column offsets advance incrementally:
+      // off(k+1) = off(k) + (no - k).
       bool ok = true;
       double dprev = 0.0, invd_prev = 0.0;
+      int oj = 0;                                   // tri_off(no, j)
       for (int j = 0; j < no; j++) {
-        const int oj = tri_off(no, j);
+        double dj = 0.0;
+        const int nterm = j - 1;                    // terms k = 0 .. j-2 come from stored columns
         ex.par([&](int l) {
-          double a_ = (l >= j && l < no) ? L.M[oj + (l - j)] : 0.0;
-          if (l == j) a_ = a_ + nu;
-          acc[l] = a_;
-        });
-        // terms k = 0 .. j-2: columns already stored (scaled) in Lk
-        int k = 0;
-        for (; k + 8 <= j - 1; k += 8) {
-          ex.par([&](int l) {
+          const int li = l < no ? l : no - 1;        // clamp idle lanes into range
+          double s_ = L.M[oj + (li - j)];
+          if (l == j) s_ = s_ + nu;
+          int ok_ = 0;                               // tri_off(no, k)
+          int k = 0;
+          for (; k + 8 <= nterm; k += 8) {
             double a[8], b[8], d[8];
+            int o_ = ok_;
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int ok_ = tri_off(no, k + u); a[u] = L.Lk[ok_ + (l - (k + u))]; b[u] = L.Lk[ok_ + (j - (k + u))]; d[u] = L.Dv[k + u]; }
-            double s_ = acc[l];
+            for (int u = 0; u < 8; u++) { a[u] = L.Lk[o_ + (li - (k + u))]; b[u] = L.Lk[o_ + (j - (k + u))]; d[u] = L.Dv[k + u]; o_ += no - (k + u); }
 #pragma unroll
             for (int u = 0; u < 8; u++) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }   // k <= j-2: never the fused term
-            acc[l] = s_;
-          });
-        }
-        if (k < j - 1) {
-          ex.par([&](int l) {
+            ok_ = o_;
+          }
+          if (k < nterm) {
             double a[8], b[8], d[8];
+            int o_ = ok_;
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-              const int kk = (k + u < j - 1) ? k + u : k;       // clamp: loads stay in range
-              const int ok_ = tri_off(no, kk); a[u] = L.Lk[ok_ + (l - kk)]; b[u] = L.Lk[ok_ + (j - kk)]; d[u] = L.Dv[kk];
+              const bool in = k + u < nterm;          // uniform
+              const int kk = in ? k + u : k;
+              const int oo = in ? o_ : ok_;
+              a[u] = L.Lk[oo + (li - kk)]; b[u] = L.Lk[oo + (j - kk)]; d[u] = L.Dv[kk];
+              if (in) o_ += no - kk;
             }
-            double s_ = acc[l];
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (k + u < j - 1) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }
-            acc[l] = s_;
-          });
-        }
+            for (int u = 0; u < 8; u++) if (k + u < nterm) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }
+          }
+          acc[l] = s_;
+        });
         if (j > 0) {
-          // finish column j-1: L[i][j-1] = lij * invD (math.h:49), keep it for the last term
-          const int op = tri_off(no, j - 1);
+          // finish column j-1: L[i][j-1] = lij * invD (math.h:49); its last term for column j
+          const int op = oj - (no - (j - 1));        // tri_off(no, j-1)
           ex.par([&](int l) {
             const double lp = accprev[l] * invd_prev;
             accprev[l] = lp;
@@ -324,13 +328,11 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
           const double bj = ex.lane_bcast(accprev, j);
           const bool fz = fold_fused(j - 1, j);
           ex.par([&](int l) {
-            if (l >= j && l < no) {
-              const double tt = accprev[l] * bj;
-              acc[l] = fz ? fma(-tt, dprev, acc[l]) : acc[l] - tt * dprev;
-            }
+            const double tt = accprev[l] * bj;
+            acc[l] = fz ? fma(-tt, dprev, acc[l]) : acc[l] - tt * dprev;
           });
         }
-        const double dj = ex.lane_bcast(acc, j);
+        dj = ex.lane_bcast(acc, j);
         if (dj < 1e-12) { ok = false; break; }
         const double invd = 1.0 / dj;
         ex.par([&](int l) {
@@ -339,6 +341,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
           accprev[l] = acc[l];
         });
         dprev = dj; invd_prev = invd;
+        oj += no - j;
         ex.wsync();   // one wave: LDS traffic is in order, only the compiler needs the fence
       }
       SA_TICK(2);
@@ -375,7 +378,13 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
 #pragma unroll
               for (int u = 0; u < 8; u++) s_ = fma(-a[u], w[u], s_);
             }
-            for (; kk < no; ++kk) s_ = fma(-L.Lk[oi + (kk - i)], L.Wv[kk], s_);
+            if (kk < no) {
+              double a[8], w[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) { const int q = kk + u < no ? kk + u : kk; a[u] = L.Lk[oi + (q - i)]; w[u] = L.Wv[q]; }
+#pragma unroll
+              for (int u = 0; u < 8; u++) if (kk + u < no) s_ = fma(-a[u], w[u], s_);
+            }
           });
           ex.par([&](int l) { if (l == 0) L.Wv[i] = s_; });
           ex.wsync();
