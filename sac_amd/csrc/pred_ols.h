@@ -187,14 +187,16 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
 //    (the scaled column goes to a second triangle, Lk), leaving one barrier per column;
 //  * the element loops issue their LDS loads four elements at a time.
 struct OlsLdsFast {
-  double *X, *Wv, *Dv, *M, *Lk, *libm;
+  double *X, *Wv, *Dv, *M, *Lq, *libm;
+  // Lq: L stored square, [column k][row i] with row stride NMAX: unrolled loops address it as
+  // base + compile-time immediate (no per-load index arithmetic); M stays a packed triangle.
   SA_HD static size_t bytes(int nmax) {
-    return (size_t)(3 * nmax + 2 * tri_count(nmax) + kLibmLdsDoubles) * sizeof(double) + 16;
+    return (size_t)(3 * nmax + tri_count(nmax) + nmax * nmax + kLibmLdsDoubles) * sizeof(double) + 16;
   }
   SA_HD void carve(char *base, int nmax) {
     double *d = reinterpret_cast<double *>(base);
     X = d; d += nmax; Wv = d; d += nmax; Dv = d; d += nmax;
-    M = d; d += tri_count(nmax); Lk = d; d += tri_count(nmax);
+    M = d; d += tri_count(nmax); Lq = d; d += nmax * nmax;
     libm = d; d += kLibmLdsDoubles;
   }
 };
@@ -205,10 +207,12 @@ struct OlsLdsFast {
 // coalesced LDS read per k: column k is contiguous in the packed triangle) and row j's L[j][k]
 // (same-address broadcast read).  The reciprocal of pivot j-1 is issued before column j's first
 // j-1 terms, which do not need it, and consumed for the last term.
-template <class E>
+template <class E, int NMAX>
 SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                          double *p_out, char *lds_base, int nmax, unsigned long long *prof = nullptr) {
+                          double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
   static_assert(E::nl == 64, "one-wave path");
+  constexpr int nmax = NMAX;
+  constexpr int S = NMAX;          // row stride of Lq
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
 #define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
   constexpr int NL = 64;
@@ -224,7 +228,8 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
   ex.par([&](int l) {
     xr[l] = 0.0; breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0; accprev[l] = 0.0;
     if (l < no) { L.X[l] = 0.0; L.Wv[l] = 0.0; L.Dv[l] = 0.0; }
-    for (int e = l; e < ntri; e += NL) { L.M[e] = 0.0; L.Lk[e] = 0.0; }
+    for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
+    for (int e = l; e < S * S; e += NL) L.Lq[e] = 0.0;
     sa_stage_tables(L.libm, l, NL);
     xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
   });
@@ -287,31 +292,24 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         double dj = 0.0;
         const int nterm = j - 1;                    // terms k = 0 .. j-2 come from stored columns
         ex.par([&](int l) {
-          const int li = l < no ? l : no - 1;        // clamp idle lanes into range
-          double s_ = L.M[oj + (li - j)];
+          const int li = l < S ? l : S - 1;          // clamp idle lanes into range
+          const int lm = l < no ? l : no - 1;
+          double s_ = L.M[oj + (lm - j)];
           if (l == j) s_ = s_ + nu;
-          int ok_ = 0;                               // tri_off(no, k)
+          const double *pa = L.Lq + li;               // own row: element k at pa[k*S]
+          const double *pb = L.Lq + j;                // row j (same address in all lanes)
           int k = 0;
           for (; k + 8 <= nterm; k += 8) {
             double a[8], b[8], d[8];
-            int o_ = ok_;
 #pragma unroll
-            for (int u = 0; u < 8; u++) { a[u] = L.Lk[o_ + (li - (k + u))]; b[u] = L.Lk[o_ + (j - (k + u))]; d[u] = L.Dv[k + u]; o_ += no - (k + u); }
+            for (int u = 0; u < 8; u++) { a[u] = pa[(k + u) * S]; b[u] = pb[(k + u) * S]; d[u] = L.Dv[k + u]; }
 #pragma unroll
             for (int u = 0; u < 8; u++) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }   // k <= j-2: never the fused term
-            ok_ = o_;
           }
           if (k < nterm) {
             double a[8], b[8], d[8];
-            int o_ = ok_;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const bool in = k + u < nterm;          // uniform
-              const int kk = in ? k + u : k;
-              const int oo = in ? o_ : ok_;
-              a[u] = L.Lk[oo + (li - kk)]; b[u] = L.Lk[oo + (j - kk)]; d[u] = L.Dv[kk];
-              if (in) o_ += no - kk;
-            }
+            for (int u = 0; u < 8; u++) { a[u] = pa[(k + u) * S]; b[u] = pb[(k + u) * S]; d[u] = L.Dv[k + u]; }   // k+u < S: in range
 #pragma unroll
             for (int u = 0; u < 8; u++) if (k + u < nterm) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }
           }
@@ -319,11 +317,10 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         });
         if (j > 0) {
           // finish column j-1: L[i][j-1] = lij * invD (math.h:49); its last term for column j
-          const int op = oj - (no - (j - 1));        // tri_off(no, j-1)
           ex.par([&](int l) {
             const double lp = accprev[l] * invd_prev;
             accprev[l] = lp;
-            if (l > j - 1 && l < no) L.Lk[op + (l - (j - 1))] = lp;
+            if (l > j - 1 && l < no) L.Lq[(j - 1) * S + l] = lp;
           });
           const double bj = ex.lane_bcast(accprev, j);
           const bool fz = fold_fused(j - 1, j);
@@ -350,10 +347,9 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         ex.par([&](int l) { sreg[l] = breg[l]; });
         for (int kk = 0; kk + 1 < no; kk++) {
           const double yk = ex.lane_bcast(sreg, kk);
-          const int ok0 = tri_off(no, kk);
           ex.par([&](int l) {
             if (l > kk && l < no) {
-              const double lv = L.Lk[ok0 + (l - kk)];
+              const double lv = L.Lq[kk * S + l];
               sreg[l] = fold_fused(kk, l) ? fma(-lv, yk, sreg[l]) : sreg[l] - lv * yk;
             }
           });
@@ -366,22 +362,22 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         ex.par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS (D is no longer needed)
         ex.wsync();
         for (int i = no - 1; i >= 0; --i) {
-          const int oi = tri_off(no, i);
           double s_ = 0.0;
           ex.uni([&]() {
             s_ = L.Dv[i];
+            const double *pa = L.Lq + i * S;          // column i of L: rows kk contiguous
             int kk = i + 1;
             for (; kk + 8 <= no; kk += 8) {
               double a[8], w[8];
 #pragma unroll
-              for (int u = 0; u < 8; u++) { a[u] = L.Lk[oi + (kk + u - i)]; w[u] = L.Wv[kk + u]; }
+              for (int u = 0; u < 8; u++) { a[u] = pa[kk + u]; w[u] = L.Wv[kk + u]; }
 #pragma unroll
               for (int u = 0; u < 8; u++) s_ = fma(-a[u], w[u], s_);
             }
             if (kk < no) {
               double a[8], w[8];
 #pragma unroll
-              for (int u = 0; u < 8; u++) { const int q = kk + u < no ? kk + u : kk; a[u] = L.Lk[oi + (q - i)]; w[u] = L.Wv[q]; }
+              for (int u = 0; u < 8; u++) { const int q = kk + u < S ? kk + u : S - 1; a[u] = pa[q]; w[u] = L.Wv[q]; }
 #pragma unroll
               for (int u = 0; u < 8; u++) if (kk + u < no) s_ = fma(-a[u], w[u], s_);
             }

@@ -38,7 +38,9 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     double *pl = plpc + (size_t)ch_self * n, *ps = psum + (size_t)ch_self * n;
     if (p.n_ols > kMaxOLS) return -1;
     {
-      if (p.n_ols <= 64) { std::vector<char> lds(OlsLdsFast::bytes(64)); ExecEmu<64> ex; ols_stage_fast(ex, p, self, other, n, pl, lds.data(), 64); }
+      if (p.n_ols <= 16) { std::vector<char> lds(OlsLdsFast::bytes(16)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, 16>(ex, p, self, other, n, pl, lds.data()); }
+      else if (p.n_ols <= 32) { std::vector<char> lds(OlsLdsFast::bytes(32)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, 32>(ex, p, self, other, n, pl, lds.data()); }
+      else if (p.n_ols <= 64) { std::vector<char> lds(OlsLdsFast::bytes(64)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, 64>(ex, p, self, other, n, pl, lds.data()); }
       else { std::vector<char> lds(OlsLds::bytes(128)); ExecEmu<128> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 128); }
     }
     std::vector<double> tab; double sp[4];
