@@ -186,6 +186,8 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
 //    handed on in a register; scaling of the column and the trailing update share one phase
 //    (the scaled column goes to a second triangle, Lk), leaving one barrier per column;
 //  * the element loops issue their LDS loads four elements at a time.
+struct DArr4 { double v[4]; };
+
 struct OlsLdsFast {
   double *X, *Wv, *Dv, *M, *Lq, *libm;
   // Lq: L stored square, [column k][row i] with row stride NMAX: unrolled loops address it as
@@ -266,12 +268,18 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         int j = 0;
         // loads are unconditional (rows above the diagonal read harmless neighbours of the packed
         // triangle), only the stores are masked
+        double *dump = L.Dv + (NMAX - 1);            // write-only slot... (Dv[NMAX-1] is rewritten by every factorisation before use)
         for (; j + 8 <= no; j += 8) {
           double m[8], xj[8];
+          int e[8];
 #pragma unroll
-          for (int u = 0; u < 8; u++) { xj[u] = L.X[j + u]; m[u] = L.M[tri_off(no, j + u) + (l - (j + u))]; }
+          for (int u = 0; u < 8; u++) { e[u] = tri_off(no, j + u) + (l - (j + u)); xj[u] = L.X[j + u]; m[u] = L.M[e[u]]; }
 #pragma unroll
-          for (int u = 0; u < 8; u++) { const double v = fma(lambda, m[u], ff * (xi * xj[u])); if (l >= j + u) L.M[tri_off(no, j + u) + (l - (j + u))] = v; }
+          for (int u = 0; u < 8; u++) {
+            const double v = fma(lambda, m[u], ff * (xi * xj[u]));
+            double *dst = (l >= j + u) ? &L.M[e[u]] : dump;      // select the address, not the lane
+            *dst = v;
+          }
         }
         for (; j < no; j++) { const int e = tri_off(no, j) + (l - j); const double v = fma(lambda, L.M[e], ff * (xi * L.X[j])); if (l >= j) L.M[e] = v; }
         breg[l] = fma(lambda, breg[l], ff * (xi * val));
@@ -345,14 +353,24 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       if (ok) {
         // forward solve: column sweep with register broadcasts
         ex.par([&](int l) { sreg[l] = breg[l]; });
-        for (int kk = 0; kk + 1 < no; kk++) {
-          const double yk = ex.lane_bcast(sreg, kk);
+        for (int k0 = 0; k0 + 1 < no; k0 += 4) {
+          typename E::template Reg<DArr4> lv;
           ex.par([&](int l) {
-            if (l > kk && l < no) {
-              const double lv = L.Lq[kk * S + l];
-              sreg[l] = fold_fused(kk, l) ? fma(-lv, yk, sreg[l]) : sreg[l] - lv * yk;
-            }
+            const int li = l < S ? l : S - 1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int kk = k0 + u < S ? k0 + u : S - 1; lv[l].v[u] = L.Lq[kk * S + li]; }
           });
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int kk = k0 + u;
+            if (kk + 1 < no) {
+              const double yk = ex.lane_bcast(sreg, kk);
+              ex.par([&](int l) {
+                const double v = fold_fused(kk, l) ? fma(-lv[l].v[u], yk, sreg[l]) : sreg[l] - lv[l].v[u] * yk;
+                if (l > kk && l < no) sreg[l] = v;
+              });
+            }
+          }
         }
         ex.par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
         SA_TICK(3);
@@ -361,30 +379,29 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         // reads issued eight at a time; only the fma sits on the dependency chain.
         ex.par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS (D is no longer needed)
         ex.wsync();
-        for (int i = no - 1; i >= 0; --i) {
-          double s_ = 0.0;
-          ex.uni([&]() {
-            s_ = L.Dv[i];
+        // One uniform instruction stream for all rows: per row a single LDS round trip (z_i, column
+        // i of L, the already stored w[i+2..]) and the fma chain; w[i+1] is carried in a register
+        // and same-wave LDS traffic is ordered, so no fence between rows.
+        ex.uni([&]() {
+          double wlast = 0.0;
+          for (int i = no - 1; i >= 0; --i) {
             const double *pa = L.Lq + i * S;          // column i of L: rows kk contiguous
+            double s_ = L.Dv[i];
             int kk = i + 1;
-            for (; kk + 8 <= no; kk += 8) {
-              double a[8], w[8];
-#pragma unroll
-              for (int u = 0; u < 8; u++) { a[u] = pa[kk + u]; w[u] = L.Wv[kk + u]; }
-#pragma unroll
-              for (int u = 0; u < 8; u++) s_ = fma(-a[u], w[u], s_);
-            }
-            if (kk < no) {
+            bool first = true;
+            for (; kk < no; kk += 8) {
               double a[8], w[8];
 #pragma unroll
               for (int u = 0; u < 8; u++) { const int q = kk + u < S ? kk + u : S - 1; a[u] = pa[q]; w[u] = L.Wv[q]; }
+              if (first) { w[0] = wlast; first = false; }
 #pragma unroll
               for (int u = 0; u < 8; u++) if (kk + u < no) s_ = fma(-a[u], w[u], s_);
             }
-          });
-          ex.par([&](int l) { if (l == 0) L.Wv[i] = s_; });
-          ex.wsync();
-        }
+            wlast = s_;
+            if (E::is_lane0()) L.Wv[i] = s_;
+          }
+        });
+        ex.wsync();
         SA_TICK(4);
       }
     }
