@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <random>
@@ -76,6 +77,7 @@ struct DevBuf {
 enum { FAM_ANALYSE = 0, FAM_TABLES, FAM_OLS, FAM_LMS, FAM_BIAS, FAM_COST, FAM_S2U, FAM_CODER, FAM_COUNT };
 
 struct TimedSpan { int fam; hipEvent_t a, b; };
+struct TraceSpan { char label[64]; hipEvent_t a, b; };   // SACAMD_TRACE=1: per-class launch durations on stderr
 
 }  // namespace
 
@@ -123,6 +125,8 @@ struct sacamd_ctx {
   std::vector<EncOut> enc;   // [frame*nch+ch]
   // timing
   std::vector<TimedSpan> spans;
+  std::vector<TraceSpan> trace;
+  bool tracing = false;
   double fam_ms[FAM_COUNT] = {0};
   long long fam_launches[FAM_COUNT] = {0};
 };
@@ -157,7 +161,25 @@ void collect_spans(sacamd_ctx *c) {
     (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
   }
   c->spans.clear();
+  for (auto &t : c->trace) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) std::fprintf(stderr, "[sacamd trace] %s %.3f ms\n", t.label, ms);
+    (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+  }
+  c->trace.clear();
 }
+
+// optional per-launch trace on an arbitrary stream
+struct Trace {
+  sacamd_ctx *c; hipStream_t st; TraceSpan t; bool on;
+  Trace(sacamd_ctx *c_, hipStream_t st_, const char *what, int cls, int count, int n) : c(c_), st(st_), on(c_->tracing && count > 0) {
+    if (!on) return;
+    std::snprintf(t.label, sizeof(t.label), "%s class %d items %d steps %d", what, cls, count, n);
+    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, st);
+  }
+  ~Trace() { if (on) { (void)hipEventRecord(t.b, st); c->trace.push_back(t); } }
+};
 
 int sync_stream(sacamd_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -249,10 +271,10 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     return 0;
   };
   { Span sp(c, FAM_OLS);
-    int r = fork_join(4, [&](int k, hipStream_t st) { launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); });
+    int r = fork_join(4, [&](int k, hipStream_t st) { Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n); launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); });
     if (r) return r; }
   { Span sp(c, FAM_LMS);
-    int r = fork_join(3, [&](int k, hipStream_t st) { launch_lms(st, c->d_items.p, c->d_idx.p + base_lms[k], (int)idx_lms[k].size(), k, view(c), c->d_tab.p, c->d_p.p); });
+    int r = fork_join(3, [&](int k, hipStream_t st) { Trace tr(c, st, "lms", k, (int)idx_lms[k].size(), items[0].n); launch_lms(st, c->d_items.p, c->d_idx.p + base_lms[k], (int)idx_lms[k].size(), k, view(c), c->d_tab.p, c->d_p.p); });
     if (r) return r; }
   { Span sp(c, FAM_BIAS);
     launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
@@ -301,6 +323,7 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   if (hipSetDevice(device) != hipSuccess) return SACAMD_ERR_NOGPU;
   sacamd_ctx *c = new sacamd_ctx();
   c->device = device; c->nch = nch; c->max_framesize = max_framesize; c->max_frames = max_frames;
+  { const char *e = std::getenv("SACAMD_TRACE"); c->tracing = e && e[0] == '1'; }
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   for (int k = 0; k < 4; k++) {
     if (hipStreamCreate(&c->cls_stream[k]) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }

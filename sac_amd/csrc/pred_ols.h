@@ -187,19 +187,23 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
 //    (the scaled column goes to a second triangle, Lk), leaving one barrier per column;
 //  * the element loops issue their LDS loads four elements at a time.
 struct DArr4 { double v[4]; };
+constexpr int kOlsPad = 8;
 
 struct OlsLdsFast {
-  double *X, *Wv, *Dv, *M, *Lq, *libm;
-  // Lq: L stored square, [column k][row i] with row stride NMAX: unrolled loops address it as
-  // base + compile-time immediate (no per-load index arithmetic); M stays a packed triangle.
+  double *X, *Wv, *Dv, *M, *Lq, *libm, *dump;
+  // Lq: L stored column by column, [column k][row i] with row stride SP = NMAX + kOlsPad.  Rows
+  // >= n_ols of every column (including the kOlsPad padding rows) and rows <= k of column k are
+  // never written and stay 0.0: the solve loops run whole 8-term chunks and rely on those zeros
+  // (a term with a zero factor leaves the fused chain unchanged), so they carry no masks.  Wv is
+  // padded the same way.  M stays a packed triangle.
   SA_HD static size_t bytes(int nmax) {
-    return (size_t)(3 * nmax + tri_count(nmax) + nmax * nmax + kLibmLdsDoubles) * sizeof(double) + 16;
+    return (size_t)(nmax + 2 * (nmax + kOlsPad) + tri_count(nmax) + nmax * (nmax + kOlsPad) + kLibmLdsDoubles + 2) * sizeof(double) + 16;
   }
   SA_HD void carve(char *base, int nmax) {
     double *d = reinterpret_cast<double *>(base);
-    X = d; d += nmax; Wv = d; d += nmax; Dv = d; d += nmax;
-    M = d; d += tri_count(nmax); Lq = d; d += nmax * nmax;
-    libm = d; d += kLibmLdsDoubles;
+    X = d; d += nmax; Wv = d; d += nmax + kOlsPad; Dv = d; d += nmax + kOlsPad;
+    M = d; d += tri_count(nmax); Lq = d; d += nmax * (nmax + kOlsPad);
+    libm = d; d += kLibmLdsDoubles; dump = d; d += 2;
   }
 };
 
@@ -214,7 +218,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
                           double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
   static_assert(E::nl == 64, "one-wave path");
   constexpr int nmax = NMAX;
-  constexpr int S = NMAX;          // row stride of Lq
+  constexpr int S = NMAX + kOlsPad;   // column stride of Lq (rows NMAX.. are zero padding)
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
 #define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
   constexpr int NL = 64;
@@ -229,9 +233,10 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
 
   ex.par([&](int l) {
     xr[l] = 0.0; breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0; accprev[l] = 0.0;
-    if (l < no) { L.X[l] = 0.0; L.Wv[l] = 0.0; L.Dv[l] = 0.0; }
+    if (l < no) L.X[l] = 0.0;
+    for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
     for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
-    for (int e = l; e < S * S; e += NL) L.Lq[e] = 0.0;
+    for (int e = l; e < NMAX * S; e += NL) L.Lq[e] = 0.0;
     sa_stage_tables(L.libm, l, NL);
     xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
   });
@@ -268,7 +273,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         int j = 0;
         // loads are unconditional (rows above the diagonal read harmless neighbours of the packed
         // triangle), only the stores are masked
-        double *dump = L.Dv + (NMAX - 1);            // write-only slot... (Dv[NMAX-1] is rewritten by every factorisation before use)
+        double *dump = L.dump;                       // write-only slot
         for (; j + 8 <= no; j += 8) {
           double m[8], xj[8];
           int e[8];
@@ -296,30 +301,44 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       bool ok = true;
       double dprev = 0.0, invd_prev = 0.0;
       int oj = 0;                                   // tri_off(no, j)
+      // Column j's stored-column terms k = 0 .. j-2 run as whole 8-term chunks.  D[k] is published
+      // one column late (D[j-1] in column j's finish phase) and D is cleared first, so the chunk
+      // terms k >= j-1 multiply by D[k] == 0 and leave the chain untouched; no tail masks.
+      ex.par([&](int l) { for (int e = l; e < NMAX + kOlsPad; e += NL) L.Dv[e] = 0.0; });
+      ex.wsync();
       for (int j = 0; j < no; j++) {
         double dj = 0.0;
-        const int nterm = j - 1;                    // terms k = 0 .. j-2 come from stored columns
+        const int nchunk = (j + 6) >> 3;            // ceil((j-1)/8); 8*nchunk <= NMAX
         ex.par([&](int l) {
-          const int li = l < S ? l : S - 1;          // clamp idle lanes into range
+          const int li = l < S ? l : S - 1;          // idle lanes read a padding row
           const int lm = l < no ? l : no - 1;
           double s_ = L.M[oj + (lm - j)];
           if (l == j) s_ = s_ + nu;
           const double *pa = L.Lq + li;               // own row: element k at pa[k*S]
           const double *pb = L.Lq + j;                // row j (same address in all lanes)
-          int k = 0;
-          for (; k + 8 <= nterm; k += 8) {
-            double a[8], b[8], d[8];
+          struct Fc { double a[8], b[8], d[8]; };
+          auto ld = [&](Fc &c, int m) {
+            const int k = 8 * m;
 #pragma unroll
-            for (int u = 0; u < 8; u++) { a[u] = pa[(k + u) * S]; b[u] = pb[(k + u) * S]; d[u] = L.Dv[k + u]; }
+            for (int u = 0; u < 8; u++) { c.a[u] = pa[(k + u) * S]; c.b[u] = pb[(k + u) * S]; c.d[u] = L.Dv[k + u]; }
+          };
+          auto ac = [&](double v, const Fc &c) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }   // k <= j-2: never the fused term
-          }
-          if (k < nterm) {
-            double a[8], b[8], d[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { a[u] = pa[(k + u) * S]; b[u] = pb[(k + u) * S]; d[u] = L.Dv[k + u]; }   // k+u < S: in range
-#pragma unroll
-            for (int u = 0; u < 8; u++) if (k + u < nterm) { const double tt = a[u] * b[u]; s_ = s_ - tt * d[u]; }
+            for (int u = 0; u < 8; u++) { const double tt = c.a[u] * c.b[u]; v = v - tt * c.d[u]; }   // k <= j-2: never the fused term
+            return v;
+          };
+          if (nchunk > 0) {
+            Fc A, B;
+            ld(A, 0);
+            int m = 0;
+            while (true) {                            // double-buffered: chunk m+1 loads under chunk m's chain
+              if (m + 1 < nchunk) ld(B, m + 1);
+              s_ = ac(s_, A);
+              if (++m >= nchunk) break;
+              if (m + 1 < nchunk) ld(A, m + 1);
+              s_ = ac(s_, B);
+              if (++m >= nchunk) break;
+            }
           }
           acc[l] = s_;
         });
@@ -329,6 +348,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
             const double lp = accprev[l] * invd_prev;
             accprev[l] = lp;
             if (l > j - 1 && l < no) L.Lq[(j - 1) * S + l] = lp;
+            if (l == 0) L.Dv[j - 1] = dprev;
           });
           const double bj = ex.lane_bcast(accprev, j);
           const bool fz = fold_fused(j - 1, j);
@@ -342,7 +362,6 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         const double invd = 1.0 / dj;
         ex.par([&](int l) {
           if (l == j) invd_mine[l] = invd;
-          if (l == 0) L.Dv[j] = dj;
           accprev[l] = acc[l];
         });
         dprev = dj; invd_prev = invd;
@@ -358,7 +377,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
           ex.par([&](int l) {
             const int li = l < S ? l : S - 1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int kk = k0 + u < S ? k0 + u : S - 1; lv[l].v[u] = L.Lq[kk * S + li]; }
+            for (int u = 0; u < 4; u++) { const int kk = k0 + u < NMAX ? k0 + u : NMAX - 1; lv[l].v[u] = L.Lq[kk * S + li]; }
           });
 #pragma unroll
           for (int u = 0; u < 4; u++) {
@@ -379,23 +398,39 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         // reads issued eight at a time; only the fma sits on the dependency chain.
         ex.par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS (D is no longer needed)
         ex.wsync();
-        // One uniform instruction stream for all rows: per row a single LDS round trip (z_i, column
-        // i of L, the already stored w[i+2..]) and the fma chain; w[i+1] is carried in a register
-        // and same-wave LDS traffic is ordered, so no fence between rows.
+        // One uniform instruction stream for all rows; row i runs ceil((no-1-i)/8) whole chunks
+        // starting at term i+1 (the rows >= no of column i and of w are zero padding).  w[i+1]
+        // is carried in a register; same-wave LDS traffic is ordered, so no fence between rows.
         ex.uni([&]() {
+          struct Bc { double a[8], w[8]; };
           double wlast = 0.0;
           for (int i = no - 1; i >= 0; --i) {
-            const double *pa = L.Lq + i * S;          // column i of L: rows kk contiguous
+            const double *pa = L.Lq + i * S + (i + 1);   // column i of L from row i+1 on
+            const double *pw = L.Wv + (i + 1);
+            auto ld = [&](Bc &c, int m) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) { c.a[u] = pa[8 * m + u]; c.w[u] = pw[8 * m + u]; }
+            };
+            auto ac = [&](double v, const Bc &c) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) v = fma(-c.a[u], c.w[u], v);
+              return v;
+            };
+            const int nch = (no - 1 - i + 7) >> 3;
             double s_ = L.Dv[i];
-            int kk = i + 1;
-            bool first = true;
-            for (; kk < no; kk += 8) {
-              double a[8], w[8];
-#pragma unroll
-              for (int u = 0; u < 8; u++) { const int q = kk + u < S ? kk + u : S - 1; a[u] = pa[q]; w[u] = L.Wv[q]; }
-              if (first) { w[0] = wlast; first = false; }
-#pragma unroll
-              for (int u = 0; u < 8; u++) if (kk + u < no) s_ = fma(-a[u], w[u], s_);
+            if (nch > 0) {
+              Bc A, B;
+              ld(A, 0);
+              A.w[0] = wlast;                            // w[i+1]: not yet visible in LDS
+              int m = 0;
+              while (true) {
+                if (m + 1 < nch) ld(B, m + 1);
+                s_ = ac(s_, A);
+                if (++m >= nch) break;
+                if (m + 1 < nch) ld(A, m + 1);
+                s_ = ac(s_, B);
+                if (++m >= nch) break;
+              }
             }
             wlast = s_;
             if (E::is_lane0()) L.Wv[i] = s_;

@@ -29,3 +29,15 @@ u = np.where(e < 0, -2 * e, np.where(e > 0, 2 * e - 1, 0)).astype(np.int32)
 mb = int(u.max()).bit_length() - 1
 ctx.kernel_times(); ctx.debug_bitplane(u, mb); kt = ctx.kernel_times()
 print(f"coder: {kt['coder']['ms']*1e3/(u.size*(mb+1)):.3f} us per decision ({mb+1} planes)")
+# stereo: slot-1 regressor a+b+c up to 96 (class 3 = generic two-wave path)
+raw2 = synth_pcm(n, 2, 6, 44100)
+ctx2 = api.Context(2, 882000, 1)
+ctx2.upload_i32([raw2], 882000)
+ctx2.analyse(api.make_cfg("normal"))
+for nB, nS0, nS1 in [(16, 8, 8), (32, 16, 16), (32, 24, 24), (32, 32, 32)]:
+    for opt in (0, 1):
+        g = P[:, 2].copy(); g[24] = 4; g[25] = nB; g[26] = nS0; g[27] = nS1
+        ctx2.kernel_times()
+        ctx2.debug_predict(0, g, 0, n, opt)
+        kt = ctx2.kernel_times()
+        print(f"stereo slot1 n_ols {nB+nS0+nS1:3d} k={4 if opt else 1}: ols {kt['ols']['ms']*1e3/n:8.2f}  lms {kt['lms']['ms']*1e3/n:7.2f}", flush=True)
