@@ -84,8 +84,9 @@ struct TraceSpan { char label[64]; hipEvent_t a, b; };   // SACAMD_TRACE=1: per-
 struct sacamd_ctx {
   int device = 0, nch = 0, max_framesize = 0, max_frames = 0;
   hipStream_t stream = nullptr;
-  hipStream_t cls_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // concurrent kernel classes
-  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kSide = 12;                 // side streams: concurrent launches of one stage
+  hipStream_t cls_stream[kSide] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {};
   std::string err;
   unsigned long long *d_prof = nullptr;   // debug: OLS section counters
   // staged batch
@@ -213,7 +214,8 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
       if (p.lm_n < 1 || p.lm_n > 10) return fail(c, SACAMD_ERR_ARG, "RLS order outside [1,10]");
       for (int s = 0; s < 4; s++)
         if (p.vn[s] < 1 || p.vn[s] > (8192 >> s)) return fail(c, SACAMD_ERR_ARG, "NLMS stage length outside the profile box");
-      it.ols_class = p.n_ols <= 16 ? 0 : (p.n_ols <= 32 ? 1 : (p.n_ols <= 64 ? 2 : 3));
+      it.ols_class = 0;
+      while (p.n_ols > kOlsClassMax[it.ols_class]) it.ols_class++;
       const int *vn = p.vn;
       it.lms_class = (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) ? 0
                    : (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) ? 1 : 2;
@@ -242,39 +244,68 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
   HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
   // class lists, heaviest first
-  std::vector<int> idx_ols[4], idx_lms[3];
+  std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses];
   for (int i = 0; i < count; i++) { idx_ols[items[i].ols_class].push_back(i); idx_lms[items[i].lms_class].push_back(i); }
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
   std::vector<int> flat;
-  int base_ols[4], base_lms[3];
-  for (int k = 0; k < 4; k++) {
+  int base_ols[kNumOlsClasses], base_lms[kNumLmsClasses];
+  for (int k = 0; k < kNumOlsClasses; k++) {
     std::stable_sort(idx_ols[k].begin(), idx_ols[k].end(), [&](int a, int b) { return olsw(a) > olsw(b); });
     base_ols[k] = (int)flat.size(); flat.insert(flat.end(), idx_ols[k].begin(), idx_ols[k].end());
   }
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < kNumLmsClasses; k++) {
     std::stable_sort(idx_lms[k].begin(), idx_lms[k].end(), [&](int a, int b) { return taps(a) > taps(b); });
     base_lms[k] = (int)flat.size(); flat.insert(flat.end(), idx_lms[k].begin(), idx_lms[k].end());
   }
+  // Cascade launches: the history rings are sized for the taps in use.  Each class list (sorted by
+  // taps) is cut into tiers wherever the smaller footprint of the remaining items lets one more
+  // workgroup fit on a CU (160 KB LDS); tiers are independent launches.
+  struct LmsLaunch { int cls, first, count; LmsRingCap rc; };
+  std::vector<LmsLaunch> lms_launches;
+  for (int k = 0; k < kNumLmsClasses; k++) {
+    const std::vector<int> &v = idx_lms[k];
+    const int m = (int)v.size();
+    if (!m) continue;
+    std::vector<LmsRingCap> suf(m);
+    for (int i = m - 1; i >= 0; i--)
+      for (int q = 0; q < 4; q++) suf[i].c[q] = std::max(items[v[i]].p.vn[q] + 1, i + 1 < m ? suf[i + 1].c[q] : 0);
+    auto fit = [&](int i) { return std::min(lms_max_wg_per_cu(k), (int)(160 * 1024 / lms_lds_bytes(k, suf[i]))); };
+    int first = 0;
+    for (int i = 1; i <= m; i++) {
+      if (i == m || (fit(i) > fit(first) && i - first >= 64 && m - i >= 64)) {
+        lms_launches.push_back({k, base_lms[k] + first, i - first, suf[first]});
+        first = i;
+      }
+    }
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_idx.p, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, c->stream));
   { Span sp(c, FAM_TABLES); launch_tables(c->stream, c->d_items.p, count, c->d_tab.p); }
-  // the classes of one stage are independent kernels: fork them onto side streams so that the
+  // the launches of one stage are independent kernels: fork them onto side streams so that the
   // (latency-bound, low-occupancy) launches overlap; the stage boundary is a join on the main stream
-  auto fork_join = [&](int nclass, auto &&launch_class) -> int {
+  auto fork_join = [&](int nlaunch, auto &&launch_one) -> int {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    for (int k = 0; k < nclass; k++) {
-      HIPCHK(c, hipStreamWaitEvent(c->cls_stream[k], c->ev_fork, 0));
-      launch_class(k, c->cls_stream[k]);
+    const int used = std::min(nlaunch, (int)sacamd_ctx::kSide);
+    for (int k = 0; k < used; k++) HIPCHK(c, hipStreamWaitEvent(c->cls_stream[k], c->ev_fork, 0));
+    for (int k = 0; k < nlaunch; k++) launch_one(k, c->cls_stream[k % sacamd_ctx::kSide]);
+    for (int k = 0; k < used; k++) {
       HIPCHK(c, hipEventRecord(c->ev_join[k], c->cls_stream[k]));
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
     }
     return 0;
   };
   { Span sp(c, FAM_OLS);
-    int r = fork_join(4, [&](int k, hipStream_t st) { Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n); launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); });
+    // heaviest class first: its items are the long pole of the stage
+    int r = fork_join(kNumOlsClasses, [&](int q, hipStream_t st) {
+      const int k = kNumOlsClasses - 1 - q;
+      Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n);
+      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); });
     if (r) return r; }
   { Span sp(c, FAM_LMS);
-    int r = fork_join(3, [&](int k, hipStream_t st) { Trace tr(c, st, "lms", k, (int)idx_lms[k].size(), items[0].n); launch_lms(st, c->d_items.p, c->d_idx.p + base_lms[k], (int)idx_lms[k].size(), k, view(c), c->d_tab.p, c->d_p.p); });
+    int r = fork_join((int)lms_launches.size(), [&](int q, hipStream_t st) {
+      const LmsLaunch &ll = lms_launches[q];
+      Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024));
+      launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p); });
     if (r) return r; }
   { Span sp(c, FAM_BIAS);
     launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
@@ -325,7 +356,7 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   c->device = device; c->nch = nch; c->max_framesize = max_framesize; c->max_frames = max_frames;
   { const char *e = std::getenv("SACAMD_TRACE"); c->tracing = e && e[0] == '1'; }
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < sacamd_ctx::kSide; k++) {
     if (hipStreamCreate(&c->cls_stream[k]) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
@@ -345,7 +376,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); (void)hipStreamDestroy(c->stream); }
-  for (int k = 0; k < 4; k++) { if (c->cls_stream[k]) (void)hipStreamDestroy(c->cls_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
+  for (int k = 0; k < sacamd_ctx::kSide; k++) { if (c->cls_stream[k]) (void)hipStreamDestroy(c->cls_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
@@ -587,7 +618,9 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
     { Span sp(c, FAM_OLS); launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (plpc) HIPCHK(c, hipMemcpy(plpc + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    { Span sp(c, FAM_LMS); launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, view(c), c->d_tab.p, c->d_p.p); }
+    { Span sp(c, FAM_LMS);
+      LmsRingCap rc; for (int q = 0; q < 4; q++) rc.c[q] = items[i].p.vn[q] + 1;
+      launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, rc, view(c), c->d_tab.p, c->d_p.p); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
   }

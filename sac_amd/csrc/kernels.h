@@ -22,7 +22,10 @@ void launch_analyse_i32(hipStream_t s, int nframes, int nch, const int *d_raw, l
 // ---- predictor stages (kernels_pred.hip)
 void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab);
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p);
-void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, PcmView v,
+struct LmsRingCap { int c[4]; };   // per-stage history ring capacity (doubles) of one launch
+size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc);
+int lms_max_wg_per_cu(int lms_class);          // register-file bound on resident workgroups per CU
+void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, double *d_p);
 void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
                  const double *d_p, int *d_err, int *d_pred /*nullable*/);

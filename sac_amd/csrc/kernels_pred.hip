@@ -65,15 +65,22 @@ static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_id
 
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p) {
   if (count <= 0) return;
-  if (ols_class == 0) launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p);
-  else if (ols_class == 1) launch_ols_c<64, 32>(s, d_items, d_idx, count, v, d_p);
-  else if (ols_class == 2) launch_ols_c<64, 64>(s, d_items, d_idx, count, v, d_p);
-  else launch_ols_c<128, 96>(s, d_items, d_idx, count, v, d_p);
+  static_assert(kNumOlsClasses == 8 && kOlsClassMax[6] == 64 && kOlsClassMax[7] == 96, "instances below follow kOlsClassMax");
+  switch (ols_class) {
+    case 0: launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p); break;
+    case 1: launch_ols_c<64, 24>(s, d_items, d_idx, count, v, d_p); break;
+    case 2: launch_ols_c<64, 32>(s, d_items, d_idx, count, v, d_p); break;
+    case 3: launch_ols_c<64, 40>(s, d_items, d_idx, count, v, d_p); break;
+    case 4: launch_ols_c<64, 48>(s, d_items, d_idx, count, v, d_p); break;
+    case 5: launch_ols_c<64, 56>(s, d_items, d_idx, count, v, d_p); break;
+    case 6: launch_ols_c<64, 64>(s, d_items, d_idx, count, v, d_p); break;
+    default: launch_ols_c<128, 96>(s, d_items, d_idx, count, v, d_p); break;
+  }
 }
 
 // ------------------------------------------------------------------ stage 2: cascade
 template <class C>
-__global__ __launch_bounds__(256) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, double *pbuf) {
+__global__ __launch_bounds__(256) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, double *pbuf, LmsRingCap rc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WorkItem &it = items[idx[blockIdx.x]];
   const ChanParam p = it.p;
@@ -81,23 +88,34 @@ __global__ __launch_bounds__(256) void k_lms(const WorkItem *items, const int *i
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<256> ex;
-  lms_stage<ExecDev<256>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem);
+  lms_stage<ExecDev<256>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem, rc.c);
 }
 
 template <class C>
-static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, const double *d_tab, double *d_p) {
+static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, LmsRingCap rc, PcmView v, const double *d_tab, double *d_p) {
   static bool once = false;
-  const size_t bytes = LmsLds<256, C>::bytes();
-  if (!once) { hipFuncSetAttribute((const void *)k_lms<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); once = true; }
-  hipLaunchKernelGGL((k_lms<C>), dim3(count), dim3(256), bytes, s, d_items, d_idx, v, d_tab, d_p);
+  if (!once) { (void)hipFuncSetAttribute((const void *)k_lms<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LmsLds<256, C>::bytes()); once = true; }
+  const size_t bytes = LmsLds<256, C>::bytes(rc.c);
+  hipLaunchKernelGGL((k_lms<C>), dim3(count), dim3(256), bytes, s, d_items, d_idx, v, d_tab, d_p, rc);
 }
 
-void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, PcmView v,
+using LmsA = LmsClass<8, 4, 2, 1>;
+using LmsB = LmsClass<16, 8, 4, 2>;
+using LmsC = LmsClass<32, 16, 8, 4>;
+
+size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
+  return lms_class == 0 ? LmsLds<256, LmsA>::bytes(rc.c) : lms_class == 1 ? LmsLds<256, LmsB>::bytes(rc.c) : LmsLds<256, LmsC>::bytes(rc.c);
+}
+
+// one wave of the workgroup per SIMD; 512 VGPRs per SIMD lane: ~120 / ~160 / ~240 registers per class
+int lms_max_wg_per_cu(int lms_class) { return lms_class == 0 ? 4 : lms_class == 1 ? 3 : 2; }
+
+void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, double *d_p) {
   if (count <= 0) return;
-  if (lms_class == 0) launch_lms_c<LmsClass<8, 4, 2, 1>>(s, d_items, d_idx, count, v, d_tab, d_p);
-  else if (lms_class == 1) launch_lms_c<LmsClass<16, 8, 4, 2>>(s, d_items, d_idx, count, v, d_tab, d_p);
-  else launch_lms_c<LmsClass<32, 16, 8, 4>>(s, d_items, d_idx, count, v, d_tab, d_p);
+  if (lms_class == 0) launch_lms_c<LmsA>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
+  else if (lms_class == 1) launch_lms_c<LmsB>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
+  else launch_lms_c<LmsC>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
 }
 
 // ------------------------------------------------------------------ stage 3: bias + residual

@@ -14,6 +14,10 @@ namespace sacamd {
 constexpr int kNumCoefs = 58;
 constexpr int kMaxOLS = 128;    // regressor length limit of the kernels (profile box: <= 96)
 constexpr int kStages = 4;
+// regressor-length capacity of each OLS kernel instance; the last one is the two-wave generic path
+constexpr int kNumOlsClasses = 8;
+constexpr int kOlsClassMax[kNumOlsClasses] = {16, 24, 32, 40, 48, 56, 64, 96};
+constexpr int kNumLmsClasses = 3;
 
 struct ChanParam {
   // OLS
@@ -41,7 +45,7 @@ struct WorkItem {
   int slot;           // predictor slot 0/1
   int start, n;       // window [start, start+n) inside the frame
   int lms_class;      // 0/1/2 register-capacity class of the cascade kernel
-  int ols_class;      // 0: n<=16, 1: n<=32, 2: n<=64, 3: n<=96
+  int ols_class;      // index into kOlsClassMax (LDS capacity class of the OLS kernel)
   long long off_p;    // doubles: p_lpc / p_lpc+p_lms stream [n]
   long long off_err;  // int32 residual [n]
   long long off_tab;  // doubles: per stage {mutab[vn], powtab[vn]}, stages back to back

@@ -58,15 +58,21 @@ struct LmsLds {
   double *cst;               // vmu[4], sum_powtab[4]
   double *libm;              // staged log/exp tables of libm_port.h
   int *sv;
-  SA_HD static size_t bytes() {
+  // ringcap[s] >= vn[s] + 1 of every work-item of the launch (<= C::slots(s) * NL + 1): the LDS
+  // footprint follows the taps actually in use, not the register-capacity class
+  SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
-    for (int s = 0; s < 4; s++) d += (size_t)C::slots(s) * NL + 1;
+    for (int s = 0; s < 4; s++) d += (size_t)ringcap[s];
     d += 2 * (NL / 64) * 8 + 8 + 2 * kLmsChunk + 3 * kRlsMax + 8 + 10 + 8 + kLibmLdsDoubles;
     return d * sizeof(double) + kLmsChunk * sizeof(int) + 16;
   }
-  SA_HD void carve(char *base) {
+  SA_HD static size_t bytes() {
+    const int full[4] = {C::slots(0) * NL + 1, C::slots(1) * NL + 1, C::slots(2) * NL + 1, C::slots(3) * NL + 1};
+    return bytes(full);
+  }
+  SA_HD void carve(char *base, const int *ringcap) {
     double *d = reinterpret_cast<double *>(base);
-    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)C::slots(s) * NL + 1; }
+    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ringcap[s]; }
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 8;
     pin = d; d += kLmsChunk; pout = d; d += kLmsChunk;
@@ -80,12 +86,12 @@ struct LmsLds {
 
 template <class E, class C>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
-                     const int *self, int n, double *pio, char *lds_base) {
+                     const int *self, int n, double *pio, char *lds_base, const int *ringcap) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
   static_assert(kLmsChunk == NL, "chunk staging assumes one element per lane");
   LmsLds<NL, C> L;
-  L.carve(lds_base);
+  L.carve(lds_base, ringcap);
 
   typename E::template Reg<DArr<C::total>> W, MT, PT;
   typename E::template Reg<DArr<8>> acc;

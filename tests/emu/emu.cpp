@@ -18,7 +18,8 @@ template <class C>
 static void run_lms(const ChanParam &p, const double *sp, const double *tab, const int *self, int n, double *pio) {
   std::vector<char> lds(LmsLds<256, C>::bytes());
   ExecEmu<256> ex;
-  lms_stage<ExecEmu<256>, C>(ex, p, sp, tab, self, n, pio, lds.data());
+  const int rc[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};   // tight rings, as the host sizes them
+  lms_stage<ExecEmu<256>, C>(ex, p, sp, tab, self, n, pio, lds.data(), rc);
 }
 
 // samples planar [nch][total] mean-removed; stats [nch][3] = {min,max,mean}
@@ -38,9 +39,14 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     double *pl = plpc + (size_t)ch_self * n, *ps = psum + (size_t)ch_self * n;
     if (p.n_ols > kMaxOLS) return -1;
     {
-      if (p.n_ols <= 16) { std::vector<char> lds(OlsLdsFast::bytes(16)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, 16>(ex, p, self, other, n, pl, lds.data()); }
-      else if (p.n_ols <= 32) { std::vector<char> lds(OlsLdsFast::bytes(32)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, 32>(ex, p, self, other, n, pl, lds.data()); }
-      else if (p.n_ols <= 64) { std::vector<char> lds(OlsLdsFast::bytes(64)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, 64>(ex, p, self, other, n, pl, lds.data()); }
+#define EMU_OLS(NM) { std::vector<char> lds(OlsLdsFast::bytes(NM)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, NM>(ex, p, self, other, n, pl, lds.data()); }
+      if (p.n_ols <= 16) EMU_OLS(16)
+      else if (p.n_ols <= 24) EMU_OLS(24)
+      else if (p.n_ols <= 32) EMU_OLS(32)
+      else if (p.n_ols <= 40) EMU_OLS(40)
+      else if (p.n_ols <= 48) EMU_OLS(48)
+      else if (p.n_ols <= 56) EMU_OLS(56)
+      else if (p.n_ols <= 64) EMU_OLS(64)
       else { std::vector<char> lds(OlsLds::bytes(128)); ExecEmu<128> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 128); }
     }
     std::vector<double> tab; double sp[4];
