@@ -323,8 +323,13 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
             for (int u = 0; u < 8; u++) { c.a[u] = pa[(k + u) * S]; c.b[u] = pb[(k + u) * S]; c.d[u] = L.Dv[k + u]; }
           };
           auto ac = [&](double v, const Fc &c) {
+            double td[8];                             // the 16 products are independent of the chain: issue them first
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const double tt = c.a[u] * c.b[u]; v = v - tt * c.d[u]; }   // k <= j-2: never the fused term
+            for (int u = 0; u < 8; u++) td[u] = c.a[u] * c.b[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) td[u] = td[u] * c.d[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v = v - td[u];   // k <= j-2: never the fused term
             return v;
           };
           if (nchunk > 0) {
@@ -372,6 +377,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       if (ok) {
         // forward solve: column sweep with register broadcasts
         ex.par([&](int l) { sreg[l] = breg[l]; });
+#pragma unroll 1
         for (int k0 = 0; k0 + 1 < no; k0 += 4) {
           typename E::template Reg<DArr4> lv;
           ex.par([&](int l) {
@@ -404,36 +410,50 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         ex.uni([&]() {
           struct Bc { double a[8], w[8]; };
           double wlast = 0.0;
-          for (int i = no - 1; i >= 0; --i) {
-            const double *pa = L.Lq + i * S + (i + 1);   // column i of L from row i+1 on
-            const double *pw = L.Wv + (i + 1);
-            auto ld = [&](Bc &c, int m) {
+          auto ld = [&](Bc &c, int i, int m) {           // chunk m of row i: terms i+1+8m .. +7
+            const double *pa = L.Lq + i * S + (i + 1) + 8 * m;
+            const double *pw = L.Wv + (i + 1) + 8 * m;
 #pragma unroll
-              for (int u = 0; u < 8; u++) { c.a[u] = pa[8 * m + u]; c.w[u] = pw[8 * m + u]; }
-            };
-            auto ac = [&](double v, const Bc &c) {
+            for (int u = 0; u < 8; u++) { c.a[u] = pa[u]; c.w[u] = pw[u]; }
+          };
+          auto ac = [&](double v, const Bc &c) {
 #pragma unroll
-              for (int u = 0; u < 8; u++) v = fma(-c.a[u], c.w[u], v);
-              return v;
-            };
+            for (int u = 0; u < 8; u++) v = fma(-c.a[u], c.w[u], v);
+            return v;
+          };
+          // row i given its first chunk F and z_i (both loaded one row ahead)
+          auto row = [&](int i, Bc &F, double zi) {
             const int nch = (no - 1 - i + 7) >> 3;
-            double s_ = L.Dv[i];
+            double s_ = zi;
             if (nch > 0) {
               Bc A, B;
-              ld(A, 0);
-              A.w[0] = wlast;                            // w[i+1]: not yet visible in LDS
-              int m = 0;
-              while (true) {
-                if (m + 1 < nch) ld(B, m + 1);
+              if (nch > 1) ld(A, i, 1);
+              F.w[0] = wlast;                              // w[i+1]: not yet visible in LDS when F was loaded
+              s_ = ac(s_, F);
+              int m = 1;
+              while (m < nch) {
+                if (m + 1 < nch) ld(B, i, m + 1);
                 s_ = ac(s_, A);
                 if (++m >= nch) break;
-                if (m + 1 < nch) ld(A, m + 1);
+                if (m + 1 < nch) ld(A, i, m + 1);
                 s_ = ac(s_, B);
-                if (++m >= nch) break;
+                ++m;
               }
             }
             wlast = s_;
             if (E::is_lane0()) L.Wv[i] = s_;
+          };
+          Bc F0, F1;
+          double z0, z1 = 0.0;
+          int i = no - 1;
+          ld(F0, i, 0); z0 = L.Dv[i];
+          while (true) {
+            if (i > 0) { ld(F1, i - 1, 0); z1 = L.Dv[i - 1]; }
+            row(i, F0, z0);
+            if (--i < 0) break;
+            if (i > 0) { ld(F0, i - 1, 0); z0 = L.Dv[i - 1]; }
+            row(i, F1, z1);
+            if (--i < 0) break;
           }
         });
         ex.wsync();
