@@ -126,10 +126,12 @@ int sacamd_debug_cost(sacamd_ctx *ctx, int kind, const int32_t *err, int n, doub
  * [0] analyse [1] tables [2] ols [3] lms [4] bias [5] cost [6] s2u/remap [7] coder; launches in [8..15] */
 int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
 
-/* debug: on!=0 enables per-section cycle counters in the one-wave OLS kernel (slows it slightly);
- * out8 (nullable) receives the counters of the last launch:
- * [0] regressor+predict+pow [1] covariance update [2] LDL^T factor [3] forward solve [4] backward solve [5] tail */
-int sacamd_debug_ols_profile(sacamd_ctx *ctx, int on, unsigned long long *out8);
+/* debug: on!=0 enables per-section cycle counters in the predictor kernels (slows them slightly);
+ * out16 (nullable, 16 entries) receives the counters of the last launch.  One-wave OLS kernel:
+ * [0] regressor+predict+pow [1] covariance update [2] LDL^T factor [3] forward solve [4] backward solve [5] tail.
+ * Cascade kernel (wave 0): [8] tap sweep [9] wave reduction [10] barrier [11] predict+targets
+ * [12] stage gains / experts / P x [13] RLS scalars + blend [14] P update [15] closing barrier */
+int sacamd_debug_ols_profile(sacamd_ctx *ctx, int on, unsigned long long *out16);
 
 int sacamd_abi_version(void);
 

@@ -215,7 +215,7 @@ class Context:
         return c.value
 
     def ols_profile(self, on=True):
-        out = np.zeros(8, np.uint64)
+        out = np.zeros(16, np.uint64)
         self._chk(self.lib.sacamd_debug_ols_profile(self.h, int(on), _vp(out)))
         return out
 

@@ -653,8 +653,8 @@ API int sacamd_debug_cost(sacamd_ctx *c, int kind, const int32_t *err, int n, do
 API int sacamd_debug_ols_profile(sacamd_ctx *c, int on, unsigned long long *out8) {
   if (!c) return SACAMD_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  if (on && !c->d_prof) { HIPCHK(c, hipMalloc((void **)&c->d_prof, 64)); HIPCHK(c, hipMemset(c->d_prof, 0, 64)); }
-  if (out8 && c->d_prof) HIPCHK(c, hipMemcpy(out8, c->d_prof, 64, hipMemcpyDeviceToHost));
+  if (on && !c->d_prof) { HIPCHK(c, hipMalloc((void **)&c->d_prof, 128)); HIPCHK(c, hipMemset(c->d_prof, 0, 128)); }
+  if (out8 && c->d_prof) HIPCHK(c, hipMemcpy(out8, c->d_prof, 128, hipMemcpyDeviceToHost));
   if (!on && c->d_prof) { (void)hipFree(c->d_prof); c->d_prof = nullptr; }
   return 0;
 }

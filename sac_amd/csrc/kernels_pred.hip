@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_lms(const WorkItem *items, const int *i
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<256> ex;
-  lms_stage<ExecDev<256>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem, rc.c);
+  lms_stage<ExecDev<256>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem, rc.c, v.prof);
 }
 
 template <class C>

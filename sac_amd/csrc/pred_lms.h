@@ -86,7 +86,8 @@ struct LmsLds {
 
 template <class E, class C>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
-                     const int *self, int n, double *pio, char *lds_base, const int *ringcap) {
+                     const int *self, int n, double *pio, char *lds_base, const int *ringcap,
+                     unsigned long long *prof = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
   static_assert(kLmsChunk == NL, "chunk staging assumes one element per lane");
@@ -103,7 +104,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // ---- init: tables -> registers, zero rings / weights
   // wave-0 lane roles of the mixer chain: lanes 0..9 = expert e=l/5, input i=l%5 (LS_ADA weight +
   // squared-gradient EMA in registers); lanes 0..m-1 = row l of the RLS inverse covariance P.
-  typename E::template Reg<double> exw_r, exeg_r, rw_r, ph_r, xo_r, dots_r, spow_r;
+  typename E::template Reg<double> exw_r, exeg_r, rw_r, ph_r, xo_r, dots_r, spow_r, rcp_r, exz_r;
   typename E::template Reg<DArr<kRlsMax>> Prow;
   ex.par([&](int l) {
     const double *tp = tab;
@@ -125,7 +126,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     for (int s = 0; s < 4; s++) if (l == s) { L.cst[s] = p.vmu[s]; L.cst[4 + s] = sum_powtab[s]; }
     if (l < 10) L.exwm[l] = 1.0 / 5;
     if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }
-    exw_r[l] = 1.0 / 5; exeg_r[l] = 0.0; rw_r[l] = 0.0; ph_r[l] = 0.0; xo_r[l] = 0.0; dots_r[l] = 0.0; spow_r[l] = 0.0;
+    exw_r[l] = 1.0 / 5; exeg_r[l] = 0.0; rw_r[l] = 0.0; ph_r[l] = 0.0; xo_r[l] = 0.0; dots_r[l] = 0.0; spow_r[l] = 0.0; rcp_r[l] = 0.0; exz_r[l] = 0.0;
     for (int j = 0; j < kRlsMax; j++) Prow[l].v[j] = (j == l) ? 1.0 : 0.0;
   });
   ex.sync();
@@ -134,6 +135,9 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   double smw[2] = {0.5, 0.5}, smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0;
 
   const double lo = (double)p.lo, hi = (double)p.hi;
+  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
+#define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
+  if (prof) tc = E::clock();
 
   for (int t0 = 0; t0 < n; t0 += kLmsChunk) {
     // ---- stage a chunk of p_lpc / target in, flush the previous chunk of p_lpc+p_lms out
@@ -168,11 +172,17 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           acc[l].v[s] = d; acc[l].v[4 + s] = sp;
         }
       });
-      ex.template wave_sum<8>(acc);
-      ex.par([&](int l) {
-        if ((l & 63) == 0) for (int q = 0; q < 8; q++) L.part[(par * NW + (l >> 6)) * 8 + q] = acc[l].v[q];
+      SA_TICK(0);
+      ex.wave_sum8x(acc);
+      SA_TICK(1);
+      ex.par([&](int l) {   // lane 16r of each wave holds the wave totals of values 2r, 2r+1
+        if ((l & 15) == 0) {
+          double *dst = L.part + (par * NW + (l >> 6)) * 8 + 2 * ((l >> 4) & 3);
+          dst[0] = acc[l].v[0]; dst[1] = acc[l].v[1];
+        }
       });
       ex.sync();
+      SA_TICK(2);
       // ---- B: mixer chain on wave 0, lane-parallel where the algebra allows
       ex.leader_par([&](int l) {
         if (l < 4) {   // cross-wave totals of stage l, waves in order
@@ -204,14 +214,17 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           p_prefix = fma(wgt, pl[i], p_prefix);
         }
       });
+      SA_TICK(3);
       ex.leader_par([&](int l) {
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-          if (l == s) {   // NLMS_Stream::Update scalar part (ls.h:47-48) + history push, stage s on lane s
-            L.bc[s] = L.cst[s] * (bp[s] - dots_r[l]) * L.cst[4 + s] / (spow_r[l] + 1.0);
-            int np = pos[s] - 1; if (np < 0) np += cap[s];
-            L.ring[s][np] = bp[s];
-          }
+        if (l < 4) {   // NLMS_Stream::Update scalar part (ls.h:47-48) + history push, stage l on lane l
+          const double bps = l == 0 ? bp[0] : (l == 1 ? bp[1] : (l == 2 ? bp[2] : bp[3]));
+          const int ps = l == 0 ? pos[0] : (l == 1 ? pos[1] : (l == 2 ? pos[2] : pos[3]));
+          const int cs = l == 0 ? cap[0] : (l == 1 ? cap[1] : (l == 2 ? cap[2] : cap[3]));
+          double *rg = l == 0 ? L.ring[0] : (l == 1 ? L.ring[1] : (l == 2 ? L.ring[2] : L.ring[3]));
+          L.bc[l] = L.cst[l] * (bps - dots_r[l]) * L.cst[4 + l] / (spow_r[l] + 1.0);
+          int np = ps - 1; if (np < 0) np += cs;
+          rg[np] = bps;
+        }
         if (l < 10) {  // LS_ADA experts (ls.h:224-236): expert e = l/5 (0: L1 loss, 1: L2), input i = l%5
           const int e = l >= 5, i = l - 5 * e;
           const double error = target - (e ? ep[1] : ep[0]);
@@ -229,31 +242,40 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         }
       });
       ex.wsync();
-      double denom = 0.0, inv_alpha = 0.0, rerr = 0.0;
+      SA_TICK(4);
+      double denom = 0.0, inv_alpha = 0.0, rerr = 0.0, alpha = 0.0, phi = 0.0, zm[2] = {0, 0}, maxz = 0.0;
       ex.leader([&]() {   // RLS::Update scalars + ALC (rls.cpp:28-46, rls.h:21-39)
         rerr = bp[4] - rpx;
-        const double phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8);
+        phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8);
         const double err2 = rerr * rerr;
         const double R = fmax(S0 - S1, 1e-5);
         const double nis = err2 / (phi + R);
         const double mm = sa_exp_t(-p.lm_alpha * nis, exptab);
-        const double alpha = fma(0.999 - 0.99, mm, 0.99);
-        denom = 1. / (alpha + phi);
-        inv_alpha = 1.0 / alpha;
+        alpha = fma(0.999 - 0.99, mm, 0.99);
         S0 = fma(0.95, S0, (1.0 - 0.95) * err2);
         S1 = fma(0.95, S1, (1.0 - 0.95) * phi);
         // BlendExp<RunSumEMA>::Update (blend.h:31-90)
-        double zm[2];
         for (int e = 0; e < 2; e++) {
           const double loss = fabs(target - ep[e]);
           smrs[e] = fma(0.95, smrs[e], (1.0 - 0.95) * (-loss));
           zm[e] = 1.0 * smrs[e];
         }
-        const double maxz = fmax(zm[0], zm[1]);
-        const double w0 = sa_exp_t(zm[0] - maxz, exptab), w1 = sa_exp_t(zm[1] - maxz, exptab);
+        maxz = fmax(zm[0], zm[1]);
+      });
+      // independent reciprocals / exponentials: one instruction stream, lanes 0 and 1
+      ex.leader_par([&](int l) {
+        if (l < 2) {
+          rcp_r[l] = 1.0 / (l == 0 ? alpha + phi : alpha);
+          exz_r[l] = sa_exp_t((l == 0 ? zm[0] : zm[1]) - maxz, exptab);
+        }
+      });
+      ex.leader([&]() {
+        denom = ex.lane_bcast(rcp_r, 0); inv_alpha = ex.lane_bcast(rcp_r, 1);
+        const double w0 = ex.lane_bcast(exz_r, 0), w1 = ex.lane_bcast(exz_r, 1);
         const double inv = 1.0 / (w0 + w1);
         smw[0] = w0 * inv; smw[1] = w1 * inv;
       });
+      SA_TICK(5);
       ex.leader_par([&](int l) {
         if (l < 10) L.exwm[l] = exw_r[l];
         if (l < m) {   // P / w update of row l (rls.cpp:47-56); both triangles get the same bits
@@ -269,9 +291,13 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         if (l < m) { L.rw[l] = rw_r[l]; L.rx[l] = l == 0 ? bp[4] : xo_r[l]; }   // RollBack(x, val), rls.cpp:64
       });
       for (int s = 0; s < 4; s++) { pos[s] -= 1; if (pos[s] < 0) pos[s] += cap[s]; }
+      SA_TICK(6);
       ex.sync();
+      SA_TICK(7);
     }
   }
+  if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[8 + i] = tp[i]; });
+#undef SA_TICK
   // flush the last chunk
   ex.par([&](int l) {
     const int t0 = ((n - 1) / kLmsChunk) * kLmsChunk;

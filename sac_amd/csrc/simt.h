@@ -62,6 +62,28 @@ struct ExecEmu {
         for (int l = 0; l < NL; l++) r[l].v[q] = t[l];
       }
   }
+  // transpose-reduce of 8 values per lane within each 64-lane wave: afterwards lane 16*r of the
+  // wave (r = 0..3) holds the wave totals of values 2r and 2r+1 in v[0], v[1] (other lanes and
+  // slots: unspecified).  Summation tree, per value, over the wave's lanes:
+  //   b[i] = (x[i] + x[i+32]) + (x[i+16] + x[i+48]),  i < 16
+  //   c[i] = b[i] + b[(i+8) % 16];  d[i] = c[i] + c[7-i];  total = (d[0] + d[1]) + (d[2] + d[3])
+  template <class R> void wave_sum8x(R &r) {
+    static_assert(NL % 64 == 0, "whole waves");
+    for (int w = 0; w < NL / 64; w++) {
+      double tot[8];
+      for (int q = 0; q < 8; q++) {
+        double b[16], c[8], d[4];
+        for (int i = 0; i < 16; i++) {
+          const int l = w * 64 + i;
+          b[i] = (r[l].v[q] + r[l + 32].v[q]) + (r[l + 16].v[q] + r[l + 48].v[q]);
+        }
+        for (int i = 0; i < 8; i++) c[i] = b[i] + b[i + 8];
+        for (int i = 0; i < 4; i++) d[i] = c[i] + c[7 - i];
+        tot[q] = (d[0] + d[1]) + (d[2] + d[3]);
+      }
+      for (int rr = 0; rr < 4; rr++) { r[w * 64 + 16 * rr].v[0] = tot[2 * rr]; r[w * 64 + 16 * rr].v[1] = tot[2 * rr + 1]; }
+    }
+  }
   // butterfly within waves of 64 (or NL if smaller), then sequential over waves
   void allsum(Reg<double> &r, double *scratch /*>= NL/64 doubles*/) {
     constexpr int W = NL < 64 ? NL : 64;
@@ -100,6 +122,36 @@ struct ExecDev {
     for (int d = W / 2; d >= 1; d >>= 1) {
 #pragma unroll
       for (int q = 0; q < K; q++) r.v.v[q] = r.v.v[q] + __shfl_xor(r.v.v[q], d, 64);
+    }
+  }
+  // see ExecEmu::wave_sum8x.  v_permlane32_swap / v_permlane16_swap halve the value count while
+  // folding lane halves / 16-lane rows; the last four levels are DPP moves inside a row.
+  template <int CTRL> static SA_D double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+  template <class R> SA_D void wave_sum8x(R &r) {
+    double *v = r.v.v;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {     // A' = [A.lo | B.lo], B' = [A.hi | B.hi]
+      const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v[j]), (unsigned)__double2loint(v[j + 4]), false, false);
+      const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v[j]), (unsigned)__double2hiint(v[j + 4]), false, false);
+      v[j] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {     // A' = rows [A0 B0 A2 B2], B' = rows [A1 B1 A3 B3]
+      const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v[j]), (unsigned)__double2loint(v[j + 2]), false, false);
+      const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v[j]), (unsigned)__double2hiint(v[j + 2]), false, false);
+      v[j] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      v[j] = v[j] + dpp_f64<0x128>(v[j]);   // row_ror:8
+      v[j] = v[j] + dpp_f64<0x141>(v[j]);   // row_half_mirror
+      v[j] = v[j] + dpp_f64<0xB1>(v[j]);    // quad_perm [1,0,3,2]
+      v[j] = v[j] + dpp_f64<0x4E>(v[j]);    // quad_perm [2,3,0,1]
     }
   }
   template <class T> SA_D T lane_get(const Reg<T> &r, int k) { return __shfl(r.v, k, 64); }

@@ -21,6 +21,7 @@ for nA, nM0, taps in [(8, 0, None), (16, 0, None), (32, 0, None), (32, 16, None)
         prof = ctx.ols_profile(True).astype(float) / n
         kt = ctx.kernel_times()
         print("     ols cycles/step: predict %.0f cov %.0f factor %.0f fwd %.0f bwd %.0f tail %.0f" % tuple(prof[:6]), flush=True)
+        print("     lms cycles/step: sweep %.0f wsum %.0f bar %.0f head %.0f gains %.0f rls %.0f pupd %.0f bar2 %.0f" % tuple(prof[8:16]), flush=True)
         print(f"n_ols {nA+nM0:3d} taps {taps if taps else 'default'} k={4 if opt else 1}: ols {kt['ols']['ms']*1e3/n:8.2f}  lms {kt['lms']['ms']*1e3/n:7.2f}  bias {kt['bias']['ms']*1e3/n:6.2f}", flush=True)
 # coder latency
 rng = np.random.default_rng(0)
