@@ -115,16 +115,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 64)), help="frames per GPU per step")
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 0)),
+                    help="frames per GPU per step (0 = auto: 256, fewer when steps+warmup > 1 so that the run stays within ~15 min)")
     ap.add_argument("--seconds", type=float, default=float(os.environ.get("SAC_BENCH_SECONDS", 20.0)), help="frame length")
     ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("SAC_BENCH_GROUPS", 4)),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SAC_BENCH_GROUPS", 1)),
                     help="independent frame groups run concurrently on one GPU (own context + HIP streams each)")
     ap.add_argument("--mode", default="high")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="decode every record with the oracle afterwards (slow)")
     args = ap.parse_args()
+    if args.frames <= 0:
+        # one step of F 20-s frames costs about 115 s of latency-bound final pass + coder plus ~0.5 s per frame
+        nrun = max(1, args.steps + args.warmup)
+        per_step = 900.0 / nrun
+        args.frames = int(min(256, max(32, (per_step - 115.0 * args.seconds / 20.0) / (0.5 * args.seconds / 20.0))))
 
     import torch
 
