@@ -185,10 +185,11 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       SA_TICK(2);
       // ---- B: mixer chain on wave 0, lane-parallel where the algebra allows
       ex.leader_par([&](int l) {
-        if (l < 4) {   // cross-wave totals of stage l, waves in order
-          double a = L.part[(par * NW) * 8 + l], b = L.part[(par * NW) * 8 + 4 + l];
-          for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + l]; b = b + L.part[(par * NW + w) * 8 + 4 + l]; }
-          dots_r[l] = a; spow_r[l] = b; L.pv[l] = a;
+        if (l >= 16 && l < 20) {   // cross-wave totals of stage l-16, waves in order (lanes 16..19 own the stage gains)
+          const int s = l - 16;
+          double a = L.part[(par * NW) * 8 + s], b = L.part[(par * NW) * 8 + 4 + s];
+          for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + s]; b = b + L.part[(par * NW + w) * 8 + 4 + s]; }
+          dots_r[l] = a; spow_r[l] = b; L.pv[s] = a;
         }
       });
       ex.wsync();
@@ -216,25 +217,37 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       });
       SA_TICK(3);
       ex.leader_par([&](int l) {
-        if (l < 4) {   // NLMS_Stream::Update scalar part (ls.h:47-48) + history push, stage l on lane l
-          const double bps = l == 0 ? bp[0] : (l == 1 ? bp[1] : (l == 2 ? bp[2] : bp[3]));
-          const int ps = l == 0 ? pos[0] : (l == 1 ? pos[1] : (l == 2 ? pos[2] : pos[3]));
-          const int cs = l == 0 ? cap[0] : (l == 1 ? cap[1] : (l == 2 ? cap[2] : cap[3]));
-          double *rg = l == 0 ? L.ring[0] : (l == 1 ? L.ring[1] : (l == 2 ? L.ring[2] : L.ring[3]));
-          L.bc[l] = L.cst[l] * (bps - dots_r[l]) * L.cst[4 + l] / (spow_r[l] + 1.0);
-          int np = ps - 1; if (np < 0) np += cs;
-          rg[np] = bps;
+        // lanes 16..19: NLMS_Stream::Update scalar part (ls.h:47-48) + history push of stage l-16;
+        // lanes 0..9: LS_ADA experts (ls.h:224-236), expert e = l/5 (0: L1 loss, 1: L2), input i = l%5.
+        // Both end in one division, issued once for all of them.
+        const bool isg = l >= 16 && l < 20, ise = l < 10;
+        const int sl = l - 16;
+        double num = 0.0, den = 1.0, grad = 0.0, bps = 0.0;
+        if (isg) {
+          bps = sl == 0 ? bp[0] : (sl == 1 ? bp[1] : (sl == 2 ? bp[2] : bp[3]));
+          num = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl];
+          den = spow_r[l] + 1.0;
         }
-        if (l < 10) {  // LS_ADA experts (ls.h:224-236): expert e = l/5 (0: L1 loss, 1: L2), input i = l%5
+        if (ise) {
           const int e = l >= 5, i = l - 5 * e;
           const double error = target - (e ? ep[1] : ep[0]);
           const double loss = e ? error : sgnd(error);
           const double pi_ = i == 0 ? pl[0] : (i == 1 ? pl[1] : (i == 2 ? pl[2] : (i == 3 ? pl[3] : pl[4])));
-          const double grad = loss * pi_;
+          grad = loss * pi_;
           const double beta = p.mu_mix_beta, beta1 = 1.0 - p.mu_mix_beta;
           exeg_r[l] = fma(beta, exeg_r[l], beta1 * grad * grad);
-          const double mu_scaled = p.mu_mix / (sqrt(exeg_r[l]) + 1e-5);
-          exw_r[l] = fma(mu_scaled, grad, exw_r[l]);
+          num = p.mu_mix;
+          den = sqrt(exeg_r[l]) + 1e-5;
+        }
+        const double quo = num / den;
+        if (ise) exw_r[l] = fma(quo, grad, exw_r[l]);
+        if (isg) {
+          const int ps = sl == 0 ? pos[0] : (sl == 1 ? pos[1] : (sl == 2 ? pos[2] : pos[3]));
+          const int cs = sl == 0 ? cap[0] : (sl == 1 ? cap[1] : (sl == 2 ? cap[2] : cap[3]));
+          double *rg = sl == 0 ? L.ring[0] : (sl == 1 ? L.ring[1] : (sl == 2 ? L.ring[2] : L.ring[3]));
+          L.bc[sl] = quo;
+          int np = ps - 1; if (np < 0) np += cs;
+          rg[np] = bps;
         }
         if (l < m) {   // RLS: ph = P x, row l (rls.cpp:33)
           ph_r[l] = dot_canon_m(m, [&](int j) { return Prow[l].v[j]; }, [&](int j) { return L.rx[j]; });

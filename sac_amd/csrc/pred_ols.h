@@ -407,7 +407,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         // One uniform instruction stream for all rows; row i runs ceil((no-1-i)/8) whole chunks
         // starting at term i+1 (the rows >= no of column i and of w are zero padding).  w[i+1]
         // is carried in a register; same-wave LDS traffic is ordered, so no fence between rows.
-        ex.uni([&]() {
+        ex.lane0([&]() {                                 // one lane: single-address LDS traffic, no broadcast cost
           struct Bc { double a[8], w[8]; };
           double wlast = 0.0;
           auto ld = [&](Bc &c, int i, int m) {           // chunk m of row i: terms i+1+8m .. +7
@@ -441,7 +441,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
               }
             }
             wlast = s_;
-            if (E::is_lane0()) L.Wv[i] = s_;
+            L.Wv[i] = s_;
           };
           Bc F0, F1;
           double z0, z1 = 0.0;
