@@ -189,6 +189,28 @@ SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *othe
 struct DArr4 { double v[4]; };
 constexpr int kOlsPad = 8;
 
+// rows ip = IP .. NMAX-1 of the end-anchored back-substitution (template recursion: the register
+// array wr is only ever indexed by compile-time constants)
+template <int NMAX, int S, int IP>
+struct OlsBwdRows {
+  static SA_HD __attribute__((always_inline)) void run(int no, const double *lds0, const double *lb, const double *zb, double *wb, double (&wr)[NMAX]) {
+    if constexpr (IP < NMAX) {
+      if (IP >= no) return;
+      double s_ = zb[NMAX - 1 - IP];
+      // one opaque base per row: the row's elements then sit within the 8-bit offset range of
+      // ds_read2_b64 and the compiler does not materialise one address per pair
+      int rowo = (int)(lb - lds0) + (NMAX - 1 - IP) * S;   // whole offset from the start of LDS: nothing left to fold into immediates
+      SA_OPAQUE_INT(rowo);
+      const double *rowp = lds0 + rowo;
+#pragma unroll
+      for (int kp = IP - 1; kp >= 0; kp--) s_ = fma(-rowp[NMAX - 1 - kp], wr[kp], s_);
+      wr[IP] = s_;
+      wb[NMAX - 1 - IP] = s_;
+      OlsBwdRows<NMAX, S, IP + 1>::run(no, lds0, lb, zb, wb, wr);
+    }
+  }
+};
+
 struct OlsLdsFast {
   double *X, *Wv, *Dv, *M, *Lq, *libm, *dump;
   // Lq: L stored column by column, [column k][row i] with row stride SP = NMAX + kOlsPad.  Rows
@@ -201,9 +223,12 @@ struct OlsLdsFast {
   }
   SA_HD void carve(char *base, int nmax) {
     double *d = reinterpret_cast<double *>(base);
+    // Lq comes last and Dv / Wv come after >= 16 doubles: the back-substitution addresses rows and
+    // columns relative to the LAST row (n_ols - 1) with compile-time offsets, so its base pointers
+    // sit up to (NMAX - n_ols) * (stride + 1) elements below the arrays themselves
     X = d; d += nmax; Wv = d; d += nmax + kOlsPad; Dv = d; d += nmax + kOlsPad;
-    M = d; d += tri_count(nmax); Lq = d; d += nmax * (nmax + kOlsPad);
-    libm = d; d += kLibmLdsDoubles; dump = d; d += 2;
+    M = d; d += tri_count(nmax); libm = d; d += kLibmLdsDoubles; dump = d; d += 2;
+    Lq = d; d += nmax * (nmax + kOlsPad);
   }
 };
 
@@ -407,54 +432,16 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
         // One uniform instruction stream for all rows; row i runs ceil((no-1-i)/8) whole chunks
         // starting at term i+1 (the rows >= no of column i and of w are zero padding).  w[i+1]
         // is carried in a register; same-wave LDS traffic is ordered, so no fence between rows.
-        ex.lane0([&]() {                                 // one lane: single-address LDS traffic, no broadcast cost
-          struct Bc { double a[8], w[8]; };
-          double wlast = 0.0;
-          auto ld = [&](Bc &c, int i, int m) {           // chunk m of row i: terms i+1+8m .. +7
-            const double *pa = L.Lq + i * S + (i + 1) + 8 * m;
-            const double *pw = L.Wv + (i + 1) + 8 * m;
-#pragma unroll
-            for (int u = 0; u < 8; u++) { c.a[u] = pa[u]; c.w[u] = pw[u]; }
-          };
-          auto ac = [&](double v, const Bc &c) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) v = fma(-c.a[u], c.w[u], v);
-            return v;
-          };
-          // row i given its first chunk F and z_i (both loaded one row ahead)
-          auto row = [&](int i, Bc &F, double zi) {
-            const int nch = (no - 1 - i + 7) >> 3;
-            double s_ = zi;
-            if (nch > 0) {
-              Bc A, B;
-              if (nch > 1) ld(A, i, 1);
-              F.w[0] = wlast;                              // w[i+1]: not yet visible in LDS when F was loaded
-              s_ = ac(s_, F);
-              int m = 1;
-              while (m < nch) {
-                if (m + 1 < nch) ld(B, i, m + 1);
-                s_ = ac(s_, A);
-                if (++m >= nch) break;
-                if (m + 1 < nch) ld(A, i, m + 1);
-                s_ = ac(s_, B);
-                ++m;
-              }
-            }
-            wlast = s_;
-            L.Wv[i] = s_;
-          };
-          Bc F0, F1;
-          double z0, z1 = 0.0;
-          int i = no - 1;
-          ld(F0, i, 0); z0 = L.Dv[i];
-          while (true) {
-            if (i > 0) { ld(F1, i - 1, 0); z1 = L.Dv[i - 1]; }
-            row(i, F0, z0);
-            if (--i < 0) break;
-            if (i > 0) { ld(F0, i - 1, 0); z0 = L.Dv[i - 1]; }
-            row(i, F1, z1);
-            if (--i < 0) break;
-          }
+        // Fully unrolled and anchored at the LAST row: with ip = no-1-i and kp = no-1-k the chain of
+        // row ip is  z'[ip] - sum_{kp = ip-1 .. 0} L'[ip][kp] w'[kp]  in exactly that order, so
+        // w' lives in registers under compile-time indices and every L element is one LDS read
+        // at a compile-time offset from a single base (no address arithmetic, no w re-reads).
+        ex.lane0([&]() {
+          double wr[NMAX];
+          const double *lb = L.Lq - (NMAX - no) * (S + 1);          // lb[(NMAX-1-ip)*S + (NMAX-1-kp)] == L[k][i]
+          const double *zb = L.Dv - (NMAX - no);                    // zb[NMAX-1-ip] == z[i]
+          double *wb = L.Wv - (NMAX - no);
+          OlsBwdRows<NMAX, S, 0>::run(no, L.X, lb, zb, wb, wr);
         });
         ex.wsync();
         SA_TICK(4);

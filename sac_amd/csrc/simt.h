@@ -22,6 +22,13 @@
 #define SA_HD inline
 #endif
 
+// hide an integer's value from the optimiser (device: it lives in one VGPR; host: no-op)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SA_OPAQUE_INT(x) asm volatile("" : "+v"(x))
+#else
+#define SA_OPAQUE_INT(x) ((void)0)
+#endif
+
 namespace sacamd {
 
 // ------------------------------------------------------------------ emulation executor
