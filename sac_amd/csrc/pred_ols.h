@@ -454,4 +454,247 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
 #undef SA_TICK
 }
 
+// ---------------------------------------------------------------------------------------------
+// Four-wave variant of ols_stage_fast for the long regressors (E::nl == 256, n_ols <= 64): same
+// arithmetic, element for element, but the LDL^T runs as a blocked left-looking factorisation
+// with panels of four columns:
+//   phase 1  wave w takes column 4p+w and runs its chain over the finished columns k < 4p
+//            (whole 8-term chunks, D[k] == 0 for the unpublished k >= 4p);
+//   phase 2  wave 0 adds the at most three in-panel terms of each column in order (the only
+//            possibly fused term, k = j-1 with j odd, is always an in-panel one), divides, and
+//            publishes the four columns and pivots.
+// The covariance update is split over the waves by column groups; regressor, prediction and the
+// two triangular solves stay on wave 0.
+template <class E, int NMAX>
+SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int *other, int n,
+                           double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
+  static_assert(E::nl == 256, "four-wave path");
+  constexpr int S = NMAX + kOlsPad;
+  constexpr int NL = 256;
+  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
+#define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
+  const int no = p.n_ols;
+  const int ntri = tri_count(no);
+  OlsLdsFast L;
+  L.carve(lds_base, NMAX);
+  double *ACC = L.Lq + NMAX * S;     // [4][64] phase-1 results
+  double *sc = ACC + 256;            // [0] forgetting factor of the step, [1] factorisation ok flag
+  const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
+
+  typename E::template Reg<double> xr, breg, sreg, zreg, invd_mine, accc, lp0, lp1, lp2, lp3;
+  typename E::template Reg<int> xnext;
+
+  ex.par([&](int l) {
+    xr[l] = 0.0; breg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; invd_mine[l] = 0.0; accc[l] = 0.0;
+    lp0[l] = 0.0; lp1[l] = 0.0; lp2[l] = 0.0; lp3[l] = 0.0;
+    if (l < no) L.X[l] = 0.0;
+    for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
+    for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
+    for (int e = l; e < NMAX * S; e += NL) L.Lq[e] = 0.0;
+    ACC[l] = 0.0;
+    if (l < 4) sc[l] = 0.0;
+    sa_stage_tables(L.libm, l, NL);
+    xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
+  });
+  ex.sync();
+
+  double esum = 0.0;
+  int km = 0;
+  const double lambda = p.lambda, nu = p.nu_eff;
+  const double one_m_lambda = 1.0 - lambda;
+
+  if (prof) tc = E::clock();
+  for (int t = 0; t < n; t++) {
+    ex.par([&](int l) {
+      if (l < 64) {
+        xr[l] = (double)xnext[l];
+        if (l < no) L.X[l] = xr[l];
+        if (l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
+      }
+    });
+    ex.sync();
+    double pred = 0.0, val = 0.0, ff = 0.0;
+    ex.leader([&]() {
+      pred = dot_canon(L.X, L.Wv, no);
+      val = (double)self[t];
+      const double e = val - pred;
+      esum = fma(p.beta_sum, esum, fabs(e));
+      const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
+      ff = one_m_lambda * c;
+    });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; } });
+    ex.sync();
+    SA_TICK(0);
+    // covariance / rhs update (ols.cpp:38-45): lane = row, wave w takes the column groups 8w, 8w+32
+    ex.par([&](int l) {
+      const int w = l >> 6, r = l & 63;
+      if (r < no) {
+        const double ffl = sc[0];
+        const double xi = L.X[r];
+        double *dump = L.dump;
+        for (int j = 8 * w; j < no; j += 32) {
+          double m[8], xj[8];
+          int e[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int jj = j + u < no ? j + u : no - 1;
+            e[u] = tri_off(no, jj) + (r - jj); xj[u] = L.X[jj]; m[u] = L.M[e[u]];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const double v = fma(lambda, m[u], ffl * (xi * xj[u]));
+            double *dst = (r >= j + u && j + u < no) ? &L.M[e[u]] : dump;
+            *dst = v;
+          }
+        }
+        if (w == 0) breg[l] = fma(lambda, breg[l], ff * (xi * val));
+      }
+    });
+    SA_TICK(1);
+    km++;
+    if (km >= p.k) {
+      km = 0;
+      ex.par([&](int l) {
+        for (int e = l; e < NMAX + kOlsPad; e += NL) L.Dv[e] = 0.0;
+        if (l == 0) sc[1] = 1.0;
+      });
+      ex.sync();                                   // M complete, D cleared
+      bool ok = true;
+      for (int p4 = 0; p4 < no; p4 += 4) {
+        const int nchunk = (p4 + 7) >> 3;           // chunks cover k < 8*nchunk <= NMAX; k >= p4 is masked by D == 0
+        ex.par([&](int l) {
+          const int w = l >> 6, r = l & 63;
+          const int j = p4 + w;
+          if (j < no) {
+            const int rm = r < no ? r : no - 1;
+            double s_ = L.M[tri_off(no, j) + (rm - j)];
+            if (r == j) s_ = s_ + nu;
+            const double *pa = L.Lq + r;              // own row: element k at pa[k*S]
+            const double *pb = L.Lq + j;              // row j
+            struct Fc { double a[8], b[8], d[8]; };
+            auto ld = [&](Fc &c, int m) {
+              const int k = 8 * m;
+#pragma unroll
+              for (int u = 0; u < 8; u++) { c.a[u] = pa[(k + u) * S]; c.b[u] = pb[(k + u) * S]; c.d[u] = L.Dv[k + u]; }
+            };
+            auto ac = [&](double v, const Fc &c) {
+              double td[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) td[u] = c.a[u] * c.b[u];
+#pragma unroll
+              for (int u = 0; u < 8; u++) td[u] = td[u] * c.d[u];
+#pragma unroll
+              for (int u = 0; u < 8; u++) v = v - td[u];
+              return v;
+            };
+            if (nchunk > 0) {
+              Fc A, B;
+              ld(A, 0);
+              int m = 0;
+              while (true) {
+                if (m + 1 < nchunk) ld(B, m + 1);
+                s_ = ac(s_, A);
+                if (++m >= nchunk) break;
+                if (m + 1 < nchunk) ld(A, m + 1);
+                s_ = ac(s_, B);
+                if (++m >= nchunk) break;
+              }
+            }
+            ACC[l] = s_;
+          }
+        });
+        ex.sync();
+        if (E::is_leader()) {
+          // phase 2 (wave 0): in-panel terms, pivots, scaled columns
+          double dq[4] = {0.0, 0.0, 0.0, 0.0};
+          int done = 0;
+          auto LP = [&](int q) -> typename E::template Reg<double> & { return q == 0 ? lp0 : (q == 1 ? lp1 : (q == 2 ? lp2 : lp3)); };
+          typename E::template Reg<DArr4> acc4;         // all four phase-1 columns in one LDS round trip
+          ex.leader_par([&](int l) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc4[l].v[c] = ACC[c * 64 + l];
+          });
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const int j = p4 + c;
+            if (j >= no || !ok) break;
+            ex.leader_par([&](int l) { accc[l] = acc4[l].v[c]; });
+#pragma unroll
+            for (int q = 0; q < c; q++) {
+              const double bq = ex.lane_bcast(LP(q), j);
+              const bool fz = (q == c - 1) && (j & 1);          // k = j-1 with j odd: the fused last term
+              const double dk = dq[q];
+              ex.leader_par([&](int l) {
+                const double tt = LP(q)[l] * bq;
+                accc[l] = fz ? fma(-tt, dk, accc[l]) : accc[l] - tt * dk;
+              });
+            }
+            const double dj = ex.lane_bcast(accc, j);
+            if (dj < 1e-12) { ok = false; break; }
+            const double invd = 1.0 / dj;
+            ex.leader_par([&](int l) {
+              const double lpc = accc[l] * invd;
+              LP(c)[l] = lpc;
+              if (l > j && l < no) L.Lq[j * S + l] = lpc;
+              if (l == j) invd_mine[l] = invd;
+            });
+            dq[c] = dj;
+            done = c + 1;
+          }
+          ex.leader_par([&](int l) {
+            if (l < done) L.Dv[p4 + l] = l == 0 ? dq[0] : (l == 1 ? dq[1] : (l == 2 ? dq[2] : dq[3]));
+            if (l == 0 && !ok) sc[1] = 0.0;
+          });
+        }
+        ex.sync();
+        ok = sc[1] != 0.0;
+        if (!ok) break;
+      }
+      SA_TICK(2);
+      if (ok && E::is_leader()) {
+        // forward solve: column sweep with register broadcasts (wave 0)
+        ex.leader_par([&](int l) { sreg[l] = breg[l]; });
+#pragma unroll 1
+        for (int k0 = 0; k0 + 1 < no; k0 += 4) {
+          typename E::template Reg<DArr4> lv;
+          ex.leader_par([&](int l) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int kk = k0 + u < NMAX ? k0 + u : NMAX - 1; lv[l].v[u] = L.Lq[kk * S + l]; }
+          });
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int kk = k0 + u;
+            if (kk + 1 < no) {
+              const double yk = ex.lane_bcast(sreg, kk);
+              ex.leader_par([&](int l) {
+                const double v = fold_fused(kk, l) ? fma(-lv[l].v[u], yk, sreg[l]) : sreg[l] - lv[l].v[u] * yk;
+                if (l > kk && l < no) sreg[l] = v;
+              });
+            }
+          }
+        }
+        ex.leader_par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
+        SA_TICK(3);
+        ex.leader_par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS (D is no longer needed)
+        ex.wsync();
+        ex.lane0([&]() {
+          double wr[NMAX];
+          const double *lb = L.Lq - (NMAX - no) * (S + 1);
+          const double *zb = L.Dv - (NMAX - no);
+          double *wb = L.Wv - (NMAX - no);
+          OlsBwdRows<NMAX, S, 0>::run(no, L.X, lb, zb, wb, wr);
+        });
+        ex.wsync();
+        SA_TICK(4);
+      }
+    }
+    ex.sync();
+    SA_TICK(5);
+  }
+  if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[i] = tp[i]; });
+#undef SA_TICK
+}
+
+SA_HD size_t ols_panel_lds_bytes(int nmax) { return OlsLdsFast::bytes(nmax) + (256 + 4) * sizeof(double); }
+
 }  // namespace sacamd

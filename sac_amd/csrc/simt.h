@@ -56,6 +56,7 @@ struct ExecEmu {
   template <class F> void lane0(F &&f) { f(); }
   static unsigned long long clock() { return 0; }
   static bool is_lane0() { return true; }     // inside uni(): the single emulated instance stands for lane 0
+  static bool is_leader() { return true; }    // top-level code of wave 0 (the emulator runs top-level code once)
   // per-lane code of wave 0 only; wsync orders LDS traffic inside one wave
   template <class F> void leader_par(F &&f) { for (int l = 0; l < (NL < 64 ? NL : 64); l++) f(l); }
   void wsync() {}
@@ -172,6 +173,7 @@ struct ExecDev {
   template <class F> SA_D void lane0(F &&f) { if (threadIdx.x == 0) f(); }
   static SA_D unsigned long long clock() { return __builtin_readcyclecounter(); }
   static SA_D bool is_lane0() { return threadIdx.x == 0; }
+  static SA_D bool is_leader() { return threadIdx.x < 64; }
   template <class F> SA_D void leader_par(F &&f) { if (threadIdx.x < 64) f((int)threadIdx.x); }
   SA_D void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
   // value of lane k (k uniform across the wave) -> scalar broadcast via v_readlane_b32

@@ -39,14 +39,15 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     double *pl = plpc + (size_t)ch_self * n, *ps = psum + (size_t)ch_self * n;
     if (p.n_ols > kMaxOLS) return -1;
     {
+#define EMU_OLSP(NM) { std::vector<char> lds(ols_panel_lds_bytes(NM)); ExecEmu<256> ex; ols_stage_panel<ExecEmu<256>, NM>(ex, p, self, other, n, pl, lds.data()); }
 #define EMU_OLS(NM) { std::vector<char> lds(OlsLdsFast::bytes(NM)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, NM>(ex, p, self, other, n, pl, lds.data()); }
       if (p.n_ols <= 16) EMU_OLS(16)
       else if (p.n_ols <= 24) EMU_OLS(24)
       else if (p.n_ols <= 32) EMU_OLS(32)
-      else if (p.n_ols <= 40) EMU_OLS(40)
-      else if (p.n_ols <= 48) EMU_OLS(48)
-      else if (p.n_ols <= 56) EMU_OLS(56)
-      else if (p.n_ols <= 64) EMU_OLS(64)
+      else if (p.n_ols <= 40) EMU_OLSP(40)     // as the launcher: four-wave panel path from 33 on
+      else if (p.n_ols <= 48) EMU_OLSP(48)
+      else if (p.n_ols <= 56) EMU_OLSP(56)
+      else if (p.n_ols <= 64) EMU_OLSP(64)
       else { std::vector<char> lds(OlsLds::bytes(128)); ExecEmu<128> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 128); }
     }
     std::vector<double> tab; double sp[4];
