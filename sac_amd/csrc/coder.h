@@ -345,9 +345,11 @@ SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char 
 template <class E>
 SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned char *used /*nullable: usedl, usedh*/,
                        const unsigned short *laplace, const short *g_fwd, const unsigned short *g_inv, const unsigned short *plap_init,
-                       CntL *csig0, unsigned char *out, int cap, CoderModel &M, CoderTabs &T, CoderWin &W, MapModel &MM) {
+                       CntL *csig0, unsigned char *out, int cap, CoderModel &M, const CoderTabs &T, CoderWin &W, MapModel &MM) {
+  (void)g_fwd; (void)g_inv;
+  // T (read-only tables) has been staged by the caller (coder_tabs_init) and may be shared by
+  // several streams of one workgroup
   ex.par([&](int l) {
-    coder_tabs_init(T, g_fwd, g_inv, l, E::nl);
     for (int i = l; i < 65536; i += E::nl) { csig0[i].p1 = kPScale >> 1; csig0[i].cnt = 0; }
   });
   ex.sync();

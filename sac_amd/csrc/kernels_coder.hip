@@ -5,31 +5,42 @@
 
 namespace sacamd {
 
+// Several independent streams (one wave each) per workgroup share one copy of the read-only tables.
+constexpr int kCoderStreamsPerWg = 4;   // ~116 KB of LDS: one workgroup per CU, one stream per SIMD
 struct CoderLdsLayout {
   static constexpr size_t o_tabs = 0;
-  static constexpr size_t o_model = (o_tabs + sizeof(CoderTabs) + 15) / 16 * 16;
-  static constexpr size_t o_win = (o_model + sizeof(CoderModel) + 15) / 16 * 16;
-  static constexpr size_t o_map = (o_win + sizeof(CoderWin) + 15) / 16 * 16;
-  static constexpr size_t total = (o_map + sizeof(MapModel) + 15) / 16 * 16;
+  static constexpr size_t o_stream = (o_tabs + sizeof(CoderTabs) + 15) / 16 * 16;
+  // per stream
+  static constexpr size_t s_model = 0;
+  static constexpr size_t s_win = (s_model + sizeof(CoderModel) + 15) / 16 * 16;
+  static constexpr size_t s_map = (s_win + sizeof(CoderWin) + 15) / 16 * 16;
+  static constexpr size_t s_total = (s_map + sizeof(MapModel) + 15) / 16 * 16;
+  static constexpr size_t total = o_stream + kCoderStreamsPerWg * s_total;
 };
 
 size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
 
-__global__ __launch_bounds__(64) void k_coder(const CoderJob *jobs, const int *s2u, const unsigned char *used, const unsigned short *laplace,
-                                               const short *gfwd, const unsigned short *ginv, unsigned char *state, size_t stride,
-                                               unsigned char *out, int *len) {
+__global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJob *jobs, int count, const int *s2u, const unsigned char *used,
+                                               const unsigned short *laplace, const short *gfwd, const unsigned short *ginv,
+                                               unsigned char *state, size_t stride, unsigned char *out, int *len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const CoderJob job = jobs[blockIdx.x];
   CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
-  CoderModel &M = *reinterpret_cast<CoderModel *>(smem + CoderLdsLayout::o_model);
-  CoderWin &W = *reinterpret_cast<CoderWin *>(smem + CoderLdsLayout::o_win);
-  MapModel &MM = *reinterpret_cast<MapModel *>(smem + CoderLdsLayout::o_map);
-  CntL *csig0 = reinterpret_cast<CntL *>(state + (size_t)blockIdx.x * stride);
+  coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, 64 * kCoderStreamsPerWg);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const int ji = blockIdx.x * kCoderStreamsPerWg + wave;
+  if (ji >= count) return;                       // no further workgroup-wide barriers below
+  const CoderJob job = jobs[ji];
+  char *sb = smem + CoderLdsLayout::o_stream + (size_t)wave * CoderLdsLayout::s_total;
+  CoderModel &M = *reinterpret_cast<CoderModel *>(sb + CoderLdsLayout::s_model);
+  CoderWin &W = *reinterpret_cast<CoderWin *>(sb + CoderLdsLayout::s_win);
+  MapModel &MM = *reinterpret_cast<MapModel *>(sb + CoderLdsLayout::s_map);
+  CntL *csig0 = reinterpret_cast<CntL *>(state + (size_t)ji * stride);
   const unsigned short *plap = laplace + (size_t)kLaplacePlanes * kLaplaceAvg;
-  ExecDev<64> ex;
+  ExecDevWave ex;
   const int l = coder_stream(ex, s2u + job.off_in, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace, gfwd, ginv,
                              plap, csig0, out + job.off_out, job.cap, M, T, W, MM);
-  if (threadIdx.x == 0) len[blockIdx.x] = l;
+  if ((threadIdx.x & 63) == 0) len[ji] = l;
 }
 
 void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const unsigned char *d_used,
@@ -38,8 +49,9 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   if (count <= 0) return;
   static bool once = false;
   if (!once) { (void)hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::total); once = true; }
-  hipLaunchKernelGGL(k_coder, dim3(count), dim3(64), CoderLdsLayout::total, s, d_jobs, d_s2u, d_used, d_laplace, d_fwd, d_inv, d_state,
-                     state_stride, d_out, d_len);
+  const int wgs = (count + kCoderStreamsPerWg - 1) / kCoderStreamsPerWg;
+  hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * kCoderStreamsPerWg), CoderLdsLayout::total, s, d_jobs, count, d_s2u, d_used, d_laplace,
+                     d_fwd, d_inv, d_state, state_stride, d_out, d_len);
 }
 
 // ------------------------------------------------------------------ remap

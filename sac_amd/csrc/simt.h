@@ -200,6 +200,23 @@ struct ExecDev {
     r.v = v;
   }
 };
+// One wave of a larger workgroup acting on its own (64 lanes, lane = threadIdx.x & 63).  The
+// workgroup's waves are independent streams: sync() only orders the wave's own LDS traffic.
+struct ExecDevWave {
+  static constexpr int nl = 64;
+  static constexpr bool is_device = true;
+  template <class T> struct Reg {
+    T v;
+    SA_D T &operator[](int) { return v; }
+    SA_D const T &operator[](int) const { return v; }
+  };
+  template <class F> SA_D void par(F &&f) { f((int)(threadIdx.x & 63)); }
+  SA_D void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  SA_D void wsync() { sync(); }
+  SA_D int lane_geti(const Reg<int> &r, int k) { return __builtin_amdgcn_readlane(r.v, k); }
+  template <class F> SA_D void lane0(F &&f) { if ((threadIdx.x & 63) == 0) f(); }
+};
 #endif
+
 
 }  // namespace sacamd

@@ -94,6 +94,7 @@ API int emu_bitplane(const int32_t *s2u, int n, int maxbpn, const unsigned char 
   std::vector<CntL> csig0(65536);
   CoderModel *M = new CoderModel; CoderTabs *T = new CoderTabs; CoderWin *W = new CoderWin; MapModel *MM = new MapModel;
   ExecEmu<64> ex;
+  ex.par([&](int l) { coder_tabs_init(*T, gf.data(), gi.data(), l, 64); });
   int len = coder_stream(ex, s2u, n, maxbpn, used, lap.data(), gf.data(), gi.data(), plap, csig0.data(), out, cap, *M, *T, *W, *MM);
   delete M; delete T; delete W; delete MM;
   return len;
