@@ -6,7 +6,7 @@
 namespace sacamd {
 
 // Several independent streams (one wave each) per workgroup share one copy of the read-only tables.
-constexpr int kCoderStreamsPerWg = 4;   // ~116 KB of LDS: one workgroup per CU, one stream per SIMD
+constexpr int kCoderStreamsPerWg = 4;   // upper bound; ~116 KB of LDS: one workgroup per CU, one stream per SIMD
 struct CoderLdsLayout {
   static constexpr size_t o_tabs = 0;
   static constexpr size_t o_stream = (o_tabs + sizeof(CoderTabs) + 15) / 16 * 16;
@@ -15,7 +15,7 @@ struct CoderLdsLayout {
   static constexpr size_t s_win = (s_model + sizeof(CoderModel) + 15) / 16 * 16;
   static constexpr size_t s_map = (s_win + sizeof(CoderWin) + 15) / 16 * 16;
   static constexpr size_t s_total = (s_map + sizeof(MapModel) + 15) / 16 * 16;
-  static constexpr size_t total = o_stream + kCoderStreamsPerWg * s_total;
+  static constexpr size_t bytes(int streams) { return o_stream + (size_t)streams * s_total; }
 };
 
 size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
@@ -25,10 +25,10 @@ __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJo
                                                unsigned char *state, size_t stride, unsigned char *out, int *len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
-  coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, 64 * kCoderStreamsPerWg);
+  coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   const int wave = threadIdx.x >> 6;
-  const int ji = blockIdx.x * kCoderStreamsPerWg + wave;
+  const int ji = blockIdx.x * (int)(blockDim.x >> 6) + wave;
   if (ji >= count) return;                       // no further workgroup-wide barriers below
   const CoderJob job = jobs[ji];
   char *sb = smem + CoderLdsLayout::o_stream + (size_t)wave * CoderLdsLayout::s_total;
@@ -48,9 +48,11 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
                   size_t state_stride, unsigned char *d_out, int *d_len) {
   if (count <= 0) return;
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::total); once = true; }
-  const int wgs = (count + kCoderStreamsPerWg - 1) / kCoderStreamsPerWg;
-  hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * kCoderStreamsPerWg), CoderLdsLayout::total, s, d_jobs, count, d_s2u, d_used, d_laplace,
+  if (!once) { (void)hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::bytes(kCoderStreamsPerWg)); once = true; }
+  // up to 512 streams fit as one-stream workgroups, two per CU; beyond that pack four per workgroup
+  const int spw = count <= 512 ? 1 : kCoderStreamsPerWg;
+  const int wgs = (count + spw - 1) / spw;
+  hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_used, d_laplace,
                      d_fwd, d_inv, d_state, state_stride, d_out, d_len);
 }
 
