@@ -43,9 +43,8 @@ void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab) {
 }
 
 // ------------------------------------------------------------------ stage 1: OLS
-// four-wave kernels of the two smaller capacities: ask for three workgroups per CU (<= 168 VGPRs)
 template <int NL, int NMAX>
-__global__ __launch_bounds__(NL, (NL == 256 && NMAX <= 48) ? 3 : 1) void k_ols(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
+__global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WorkItem &it = items[idx[blockIdx.x]];
   const ChanParam p = it.p;
