@@ -190,6 +190,14 @@ def main():
             allrecs = recs
         return recs, allrecs
 
+    def class_times():
+        tot = {}
+        for ctx, _, _ in groups:
+            for k, v in ctx.class_times(reset=True).items():
+                a = tot.get(k, (0.0, 0.0, 0.0))
+                tot[k] = (a[0] + v[0], a[1] + v[1], a[2] + v[2])
+        return tot
+
     def kernel_times():
         tot = None
         for ctx, _, _ in groups:
@@ -203,7 +211,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kernel_times()
+    kernel_times(); class_times()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -215,25 +223,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kt = kernel_times()
+    ct = class_times()
 
     samples_per_step = args.frames * n * 2 * world
     value = samples_per_step * args.steps / dt / 1e6
     if rank == 0:
         bps = 8 * sum(len(r) for r in allrecs) / samples_per_step
-        # ---- roofline of the dominant kernel family (HIP-event times on the context's stream)
-        dom = max(("ols", "lms", "bias", "coder", "cost"), key=lambda k: kt[k]["ms"])
+        # ---- roofline of the dominant kernel instance (HIP events on the stream each launch ran on)
         E, frac = cfg.maxnfunc, cfg.fraction
         nopt = min(n, int(np.ceil(framesize * frac)))
-        steps_per_frame_ch = E * nopt + n                       # predictor channel-steps
-        launches = max(kt[dom]["launches"], 1)
-        if dom in STAGE_BYTES:
-            alg_bytes = STAGE_BYTES[dom] * steps_per_frame_ch * 2 * args.frames * args.steps / launches
-        elif dom == "coder":
-            alg_bytes = (4 + bps / 8) * n * 2 * args.frames * args.steps / launches
-        else:
-            alg_bytes = 4 * E * nopt * 2 * args.frames * args.steps / launches
-        avg_s = kt[dom]["ms"] / 1e3 / launches
-        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        ols_nmax = (16, 24, 32, 40, 48, 56, 64, 96)
+        def kname(kind, cls):
+            if kind == "ols":
+                return f"k_ols<{64 if cls < 3 else (256 if cls < 7 else 128)},{ols_nmax[cls]}>"
+            return "k_lms<LmsClass<%s>>" % ("8,4,2,1", "16,8,4,2", "32,16,8,4")[cls]
+        cands = {}
+        for (kind, cls), (ms, launches, isteps) in ct.items():
+            cands[kname(kind, cls)] = (ms, launches, STAGE_BYTES[kind] * isteps)
+        cands["k_coder"] = (kt["coder"]["ms"], max(kt["coder"]["launches"], 1), (4 + bps / 8) * n * 2 * args.frames * args.steps)
+        dom = max(cands, key=lambda k: cands[k][0])
+        dms, dlaunch, dbytes = cands[dom]
+        avg_s = dms / 1e3 / max(dlaunch, 1)
+        achieved = dbytes / max(dlaunch, 1) / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {
             "metric": "encode MSamples/s + bps, 16-bit/44.1kHz stereo, --high; 1/2/4/8 MI355X",
             "value": value, "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,9 +258,11 @@ def main():
             "bps": bps, "x_realtime": (args.frames * world * args.seconds * args.steps) / dt,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": int(dlaunch), "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": dbytes / max(dlaunch, 1),
                          "note": "latency/fp64-VALU-bound recurrences; HBM fraction is expected to be << 1 % (SURVEY.md 8d)"},
             "kernel_ms": {k: round(v["ms"], 2) for k, v in kt.items()},
             "kernel_launches": {k: v["launches"] for k, v in kt.items()},
+            "kernel_instances_ms": {k: round(v[0], 2) for k, v in sorted(cands.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(nthreads=args.dds_n)

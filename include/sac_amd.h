@@ -126,6 +126,12 @@ int sacamd_debug_cost(sacamd_ctx *ctx, int kind, const int32_t *err, int n, doub
  * [0] analyse [1] tables [2] ols [3] lms [4] bias [5] cost [6] s2u/remap [7] coder; launches in [8..15] */
 int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
 
+/* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*8 + class)*3 + {0,1,2}] =
+ * total ms (HIP events on the launch's stream), launches, item-steps processed; kind 0 = OLS capacity
+ * classes (16,24,32 taps: k_ols<64,NMAX>; 40..64: k_ols<256,NMAX>; 96: k_ols<128,96>), kind 1 = cascade
+ * classes 0..2.  out has 48 entries. */
+int sacamd_class_times(sacamd_ctx *ctx, double *out48, int reset);
+
 /* debug: on!=0 enables per-section cycle counters in the predictor kernels (slows them slightly);
  * out16 (nullable, 16 entries) receives the counters of the last launch.  One-wave OLS kernel:
  * [0] regressor+predict+pow [1] covariance update [2] LDL^T factor [3] forward solve [4] backward solve [5] tail.

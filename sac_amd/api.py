@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "sacamd_frames_attach_s16_device", "sacamd_analyse", "sacamd_get_stats", "sacamd_evaluate",
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
-    "sacamd_kernel_times", "sacamd_debug_ols_profile", "sacamd_abi_version",
+    "sacamd_kernel_times", "sacamd_class_times", "sacamd_debug_ols_profile", "sacamd_abi_version",
 ]
 
 
@@ -218,6 +218,13 @@ class Context:
         out = np.zeros(16, np.uint64)
         self._chk(self.lib.sacamd_debug_ols_profile(self.h, int(on), _vp(out)))
         return out
+
+    def class_times(self, reset=True):
+        """per kernel instance: {(kind, class): (ms, launches, item_steps)}, kind 'ols' | 'lms'."""
+        out = np.zeros(48)
+        self._chk(self.lib.sacamd_class_times(self.h, _vp(out), int(reset)))
+        o = out.reshape(2, 8, 3)
+        return {(("ols", "lms")[k], c): tuple(o[k, c]) for k in range(2) for c in range(8) if o[k, c, 1] > 0}
 
     def kernel_times(self, reset=True):
         out = np.zeros(16)

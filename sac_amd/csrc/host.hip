@@ -77,7 +77,9 @@ struct DevBuf {
 enum { FAM_ANALYSE = 0, FAM_TABLES, FAM_OLS, FAM_LMS, FAM_BIAS, FAM_COST, FAM_S2U, FAM_CODER, FAM_COUNT };
 
 struct TimedSpan { int fam; hipEvent_t a, b; };
-struct TraceSpan { char label[64]; hipEvent_t a, b; };   // SACAMD_TRACE=1: per-class launch durations on stderr
+// per-launch timing of one predictor kernel instance (events on the launch's own stream);
+// SACAMD_TRACE=1 additionally prints each launch on stderr
+struct TraceSpan { char label[64]; int kind, cls; double item_steps; hipEvent_t a, b; };
 
 }  // namespace
 
@@ -128,6 +130,9 @@ struct sacamd_ctx {
   std::vector<TimedSpan> spans;
   std::vector<TraceSpan> trace;
   bool tracing = false;
+  // [kind 0 = OLS classes 0..7, kind 1 = cascade classes 0..2][class] -> ms, launches, item-steps
+  double cls_ms[2][kNumOlsClasses] = {}, cls_item_steps[2][kNumOlsClasses] = {};
+  long long cls_launches[2][kNumOlsClasses] = {};
   double fam_ms[FAM_COUNT] = {0};
   long long fam_launches[FAM_COUNT] = {0};
 };
@@ -164,7 +169,10 @@ void collect_spans(sacamd_ctx *c) {
   c->spans.clear();
   for (auto &t : c->trace) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) std::fprintf(stderr, "[sacamd trace] %s %.3f ms\n", t.label, ms);
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+      c->cls_ms[t.kind][t.cls] += ms; c->cls_launches[t.kind][t.cls]++; c->cls_item_steps[t.kind][t.cls] += t.item_steps;
+      if (c->tracing) std::fprintf(stderr, "[sacamd trace] %s %.3f ms\n", t.label, ms);
+    }
     (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
   }
   c->trace.clear();
@@ -173,9 +181,10 @@ void collect_spans(sacamd_ctx *c) {
 // optional per-launch trace on an arbitrary stream
 struct Trace {
   sacamd_ctx *c; hipStream_t st; TraceSpan t; bool on;
-  Trace(sacamd_ctx *c_, hipStream_t st_, const char *what, int cls, int count, int n) : c(c_), st(st_), on(c_->tracing && count > 0) {
+  Trace(sacamd_ctx *c_, hipStream_t st_, const char *what, int cls, int count, int n, double item_steps = 0.0) : c(c_), st(st_), on(count > 0) {
     if (!on) return;
     std::snprintf(t.label, sizeof(t.label), "%s class %d items %d steps %d", what, cls, count, n);
+    t.kind = what[0] == 'o' ? 0 : 1; t.cls = cls; t.item_steps = item_steps;
     (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
     (void)hipEventRecord(t.a, st);
   }
@@ -298,13 +307,15 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     // heaviest class first: its items are the long pole of the stage
     int r = fork_join(kNumOlsClasses, [&](int q, hipStream_t st) {
       const int k = kNumOlsClasses - 1 - q;
-      Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n);
+      double isteps = 0; for (int i : idx_ols[k]) isteps += items[i].n;
+      Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps);
       launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); });
     if (r) return r; }
   { Span sp(c, FAM_LMS);
     int r = fork_join((int)lms_launches.size(), [&](int q, hipStream_t st) {
       const LmsLaunch &ll = lms_launches[q];
-      Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024));
+      double isteps = 0; for (int i = 0; i < ll.count; i++) isteps += items[flat[ll.first + i]].n;
+      Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps);
       launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p); });
     if (r) return r; }
   { Span sp(c, FAM_BIAS);
@@ -650,6 +661,18 @@ API int sacamd_debug_cost(sacamd_ctx *c, int kind, const int32_t *err, int n, do
 }
 
 // debug: enable (on!=0) / read the OLS kernel's section cycle counters of the last launch
+API int sacamd_class_times(sacamd_ctx *c, double *out, int reset) {
+  if (!c || !out) return SACAMD_ERR_ARG;
+  collect_spans(c);
+  for (int kind = 0; kind < 2; kind++)
+    for (int k = 0; k < kNumOlsClasses; k++) {
+      double *o = out + (kind * kNumOlsClasses + k) * 3;
+      o[0] = c->cls_ms[kind][k]; o[1] = (double)c->cls_launches[kind][k]; o[2] = c->cls_item_steps[kind][k];
+      if (reset) { c->cls_ms[kind][k] = 0; c->cls_launches[kind][k] = 0; c->cls_item_steps[kind][k] = 0; }
+    }
+  return 0;
+}
+
 API int sacamd_debug_ols_profile(sacamd_ctx *c, int on, unsigned long long *out8) {
   if (!c) return SACAMD_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
