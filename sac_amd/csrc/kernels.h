@@ -43,7 +43,7 @@ struct CoderJob {
   int with_map;         // 1: MapEncoder prefix over used flags
   long long off_used;   // bytes into d_used (usedl at +0 .. usedh at +32769)
 };
-void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const unsigned char *d_used,
+void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map /*jobs with_map*/, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv,
                   unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len);
 size_t coder_state_bytes();

@@ -20,7 +20,7 @@ struct CoderLdsLayout {
 
 size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
 
-__global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJob *jobs, int count, const int *s2u, const unsigned char *used,
+__global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJob *jobs, int count, const int *s2u, const int *s2u_map, const unsigned char *used,
                                                const unsigned short *laplace, const short *gfwd, const unsigned short *ginv,
                                                unsigned char *state, size_t stride, unsigned char *out, int *len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -38,12 +38,13 @@ __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJo
   CntL *csig0 = reinterpret_cast<CntL *>(state + (size_t)ji * stride);
   const unsigned short *plap = laplace + (size_t)kLaplacePlanes * kLaplaceAvg;
   ExecDevWave ex;
-  const int l = coder_stream(ex, s2u + job.off_in, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace, gfwd, ginv,
+  const int *src = job.with_map ? s2u_map : s2u;       // remapped residual stream for the MapEncoder variant
+  const int l = coder_stream(ex, src + job.off_in, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace, gfwd, ginv,
                              plap, csig0, out + job.off_out, job.cap, M, T, W, MM);
   if ((threadIdx.x & 63) == 0) len[ji] = l;
 }
 
-void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const unsigned char *d_used,
+void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv, unsigned char *d_state,
                   size_t state_stride, unsigned char *d_out, int *d_len) {
   if (count <= 0) return;
@@ -52,7 +53,7 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   // up to 512 streams fit as one-stream workgroups, two per CU; beyond that pack four per workgroup
   const int spw = count <= 512 ? 1 : kCoderStreamsPerWg;
   const int wgs = (count + spw - 1) / spw;
-  hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_used, d_laplace,
+  hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_s2u_map, d_used, d_laplace,
                      d_fwd, d_inv, d_state, state_stride, d_out, d_len);
 }
 
