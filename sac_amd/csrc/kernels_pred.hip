@@ -52,18 +52,19 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
   ExecDev<NL> ex;
   if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
-  else if constexpr (NL == 256) ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
+  else if constexpr (NL == 256 || NL == 512) ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
   else ols_stage(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
 }
 
 template <int NL, int NMAX>
 static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
   static bool once = false;
-  const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : (NL == 256 ? ols_panel_lds_bytes(NMAX) : OlsLds::bytes(NMAX));
+  const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : ((NL == 256 || NL == 512) ? ols_panel_lds_bytes(NMAX, NL / 64) : OlsLds::bytes(NMAX));
   if (!once) { (void)hipFuncSetAttribute((const void *)k_ols<NL, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); once = true; }
   hipLaunchKernelGGL((k_ols<NL, NMAX>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_p);
 }
 
+constexpr int kOlsPanelThreads = 512;   // panel width 8: eight waves per work-item
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p) {
   if (count <= 0) return;
   static_assert(kNumOlsClasses == 8 && kOlsClassMax[6] == 64 && kOlsClassMax[7] == 96, "instances below follow kOlsClassMax");
@@ -71,10 +72,10 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 0: launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p); break;
     case 1: launch_ols_c<64, 24>(s, d_items, d_idx, count, v, d_p); break;
     case 2: launch_ols_c<64, 32>(s, d_items, d_idx, count, v, d_p); break;
-    case 3: launch_ols_c<256, 40>(s, d_items, d_idx, count, v, d_p); break;   // 40..64: four-wave panel factorisation
-    case 4: launch_ols_c<256, 48>(s, d_items, d_idx, count, v, d_p); break;
-    case 5: launch_ols_c<256, 56>(s, d_items, d_idx, count, v, d_p); break;
-    case 6: launch_ols_c<256, 64>(s, d_items, d_idx, count, v, d_p); break;
+    case 3: launch_ols_c<kOlsPanelThreads, 40>(s, d_items, d_idx, count, v, d_p); break;   // 40..64: multi-wave panel factorisation
+    case 4: launch_ols_c<kOlsPanelThreads, 48>(s, d_items, d_idx, count, v, d_p); break;
+    case 5: launch_ols_c<kOlsPanelThreads, 56>(s, d_items, d_idx, count, v, d_p); break;
+    case 6: launch_ols_c<kOlsPanelThreads, 64>(s, d_items, d_idx, count, v, d_p); break;
     default: launch_ols_c<128, 96>(s, d_items, d_idx, count, v, d_p); break;
   }
 }

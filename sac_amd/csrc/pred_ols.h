@@ -455,38 +455,44 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Four-wave variant of ols_stage_fast for the long regressors (E::nl == 256, n_ols <= 64): same
-// arithmetic, element for element, but the LDL^T runs as a blocked left-looking factorisation
-// with panels of four columns:
-//   phase 1  wave w takes column 4p+w and runs its chain over the finished columns k < 4p
-//            (whole 8-term chunks, D[k] == 0 for the unpublished k >= 4p);
-//   phase 2  wave 0 adds the at most three in-panel terms of each column in order (the only
-//            possibly fused term, k = j-1 with j odd, is always an in-panel one), divides, and
-//            publishes the four columns and pivots.
+// Multi-wave variant of ols_stage_fast for the long regressors (E::nl == 64*PW with PW = 4 or 8,
+// n_ols <= 64): same arithmetic, element for element, but the LDL^T runs as a blocked left-looking
+// factorisation with panels of PW columns:
+//   phase 1  wave w takes column p+w of the panel starting at p (a multiple of PW) and runs its
+//            chain over the finished columns k < p in whole 8-term chunks (for PW = 4 the last
+//            chunk may reach into the panel: those D[k] are still 0, see ols_stage_fast);
+//   phase 2  wave 0 finishes the panel right-looking: column by column it takes the pivot,
+//            divides, publishes the scaled column, and immediately applies that column's term to
+//            the later columns of the panel -- so every column still sees its terms in ascending
+//            k, and the only possibly fused term (k = j-1 with j odd) is always an in-panel one.
 // The covariance update is split over the waves by column groups; regressor, prediction and the
 // two triangular solves stay on wave 0.
+template <int N> struct OlsArr { double v[N]; };
+
 template <class E, int NMAX>
 SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int *other, int n,
                            double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
-  static_assert(E::nl == 256, "four-wave path");
+  constexpr int NL = E::nl;
+  constexpr int PW = NL / 64;
+  static_assert(PW == 4 || PW == 8, "panel width = number of waves");
   constexpr int S = NMAX + kOlsPad;
-  constexpr int NL = 256;
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
 #define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
   const int no = p.n_ols;
   const int ntri = tri_count(no);
   OlsLdsFast L;
   L.carve(lds_base, NMAX);
-  double *ACC = L.Lq + NMAX * S;     // [4][64] phase-1 results
-  double *sc = ACC + 256;            // [0] forgetting factor of the step, [1] factorisation ok flag
+  double *ACC = L.Lq + NMAX * S;     // [PW][64] phase-1 results
+  double *sc = ACC + PW * 64;        // [0] forgetting factor of the step, [1] factorisation ok flag
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
 
-  typename E::template Reg<double> xr, breg, sreg, zreg, invd_mine, accc, lp0, lp1, lp2, lp3;
+  typename E::template Reg<double> xr, breg, sreg, zreg, invd_mine, accc, lpc;
+  typename E::template Reg<OlsArr<PW>> accp;
   typename E::template Reg<int> xnext;
 
   ex.par([&](int l) {
-    xr[l] = 0.0; breg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; invd_mine[l] = 0.0; accc[l] = 0.0;
-    lp0[l] = 0.0; lp1[l] = 0.0; lp2[l] = 0.0; lp3[l] = 0.0;
+    xr[l] = 0.0; breg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; invd_mine[l] = 0.0; accc[l] = 0.0; lpc[l] = 0.0;
+    for (int c = 0; c < PW; c++) accp[l].v[c] = 0.0;
     if (l < no) L.X[l] = 0.0;
     for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
     for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
@@ -525,14 +531,14 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
     ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; } });
     ex.sync();
     SA_TICK(0);
-    // covariance / rhs update (ols.cpp:38-45): lane = row, wave w takes the column groups 8w, 8w+32
+    // covariance / rhs update (ols.cpp:38-45): lane = row, wave w takes the column groups 8w, 8w+8*PW, ..
     ex.par([&](int l) {
       const int w = l >> 6, r = l & 63;
       if (r < no) {
         const double ffl = sc[0];
         const double xi = L.X[r];
         double *dump = L.dump;
-        for (int j = 8 * w; j < no; j += 32) {
+        for (int j = 8 * w; j < no; j += 8 * PW) {
           double m[8], xj[8];
           int e[8];
 #pragma unroll
@@ -560,7 +566,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
       });
       ex.sync();                                   // M complete, D cleared
       bool ok = true;
-      for (int p4 = 0; p4 < no; p4 += 4) {
+      for (int p4 = 0; p4 < no; p4 += PW) {
         const int nchunk = (p4 + 7) >> 3;           // chunks cover k < 8*nchunk <= NMAX; k >= p4 is masked by D == 0
         ex.par([&](int l) {
           const int w = l >> 6, r = l & 63;
@@ -605,46 +611,41 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
         });
         ex.sync();
         if (E::is_leader()) {
-          // phase 2 (wave 0): in-panel terms, pivots, scaled columns
-          double dq[4] = {0.0, 0.0, 0.0, 0.0};
-          int done = 0;
-          auto LP = [&](int q) -> typename E::template Reg<double> & { return q == 0 ? lp0 : (q == 1 ? lp1 : (q == 2 ? lp2 : lp3)); };
-          typename E::template Reg<DArr4> acc4;         // all four phase-1 columns in one LDS round trip
+          // phase 2 (wave 0): right-looking inside the panel.  The other waves wait at the barrier
+          // below, so the pivots can be published as they are produced.
           ex.leader_par([&](int l) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc4[l].v[c] = ACC[c * 64 + l];
+            for (int c = 0; c < PW; c++) accp[l].v[c] = ACC[c * 64 + l];
           });
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
+          for (int c = 0; c < PW; c++) {
             const int j = p4 + c;
             if (j >= no || !ok) break;
-            ex.leader_par([&](int l) { accc[l] = acc4[l].v[c]; });
-#pragma unroll
-            for (int q = 0; q < c; q++) {
-              const double bq = ex.lane_bcast(LP(q), j);
-              const bool fz = (q == c - 1) && (j & 1);          // k = j-1 with j odd: the fused last term
-              const double dk = dq[q];
-              ex.leader_par([&](int l) {
-                const double tt = LP(q)[l] * bq;
-                accc[l] = fz ? fma(-tt, dk, accc[l]) : accc[l] - tt * dk;
-              });
-            }
+            ex.leader_par([&](int l) { accc[l] = accp[l].v[c]; });
             const double dj = ex.lane_bcast(accc, j);
             if (dj < 1e-12) { ok = false; break; }
             const double invd = 1.0 / dj;
             ex.leader_par([&](int l) {
-              const double lpc = accc[l] * invd;
-              LP(c)[l] = lpc;
-              if (l > j && l < no) L.Lq[j * S + l] = lpc;
+              const double v = accc[l] * invd;
+              lpc[l] = v;
+              if (l > j && l < no) L.Lq[j * S + l] = v;
               if (l == j) invd_mine[l] = invd;
+              if (l == 0) L.Dv[j] = dj;
             });
-            dq[c] = dj;
-            done = c + 1;
+            // term k = j of the later columns of this panel (their next term in ascending k)
+#pragma unroll
+            for (int c2 = c + 1; c2 < PW; c2++) {
+              const int j2 = p4 + c2;
+              const int jb = j2 < 64 ? j2 : 63;
+              const double bq = ex.lane_bcast(lpc, jb);
+              const bool fz = (c2 == c + 1) && (j2 & 1);          // k = j2-1 with j2 odd: the fused last term
+              ex.leader_par([&](int l) {
+                const double tt = lpc[l] * bq;
+                accp[l].v[c2] = fz ? fma(-tt, dj, accp[l].v[c2]) : accp[l].v[c2] - tt * dj;
+              });
+            }
           }
-          ex.leader_par([&](int l) {
-            if (l < done) L.Dv[p4 + l] = l == 0 ? dq[0] : (l == 1 ? dq[1] : (l == 2 ? dq[2] : dq[3]));
-            if (l == 0 && !ok) sc[1] = 0.0;
-          });
+          ex.leader_par([&](int l) { if (l == 0 && !ok) sc[1] = 0.0; });
         }
         ex.sync();
         ok = sc[1] != 0.0;
@@ -695,6 +696,6 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
 #undef SA_TICK
 }
 
-SA_HD size_t ols_panel_lds_bytes(int nmax) { return OlsLdsFast::bytes(nmax) + (256 + 4) * sizeof(double); }
+SA_HD size_t ols_panel_lds_bytes(int nmax, int waves) { return OlsLdsFast::bytes(nmax) + (size_t)(waves * 64 + 4) * sizeof(double); }
 
 }  // namespace sacamd
