@@ -64,7 +64,7 @@ static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_id
   hipLaunchKernelGGL((k_ols<NL, NMAX>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_p);
 }
 
-constexpr int kOlsPanelThreads = 512;   // panel width 8: eight waves per work-item
+constexpr int kOlsPanelThreads = 256;   // panel width 4 (8 waves measured slower: one workgroup per CU, and a barrier-parked wave sharing the SIMD of wave 0 doubles the time of its serial solve)
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p) {
   if (count <= 0) return;
   static_assert(kNumOlsClasses == 8 && kOlsClassMax[6] == 64 && kOlsClassMax[7] == 96, "instances below follow kOlsClassMax");

@@ -39,7 +39,7 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     double *pl = plpc + (size_t)ch_self * n, *ps = psum + (size_t)ch_self * n;
     if (p.n_ols > kMaxOLS) return -1;
     {
-#define EMU_OLSP(NM) { std::vector<char> lds(ols_panel_lds_bytes(NM, 8)); ExecEmu<512> ex; ols_stage_panel<ExecEmu<512>, NM>(ex, p, self, other, n, pl, lds.data()); }
+#define EMU_OLSP(NM) { std::vector<char> lds(ols_panel_lds_bytes(NM, 4)); ExecEmu<256> ex; ols_stage_panel<ExecEmu<256>, NM>(ex, p, self, other, n, pl, lds.data()); }
 #define EMU_OLS(NM) { std::vector<char> lds(OlsLdsFast::bytes(NM)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, NM>(ex, p, self, other, n, pl, lds.data()); }
       if (p.n_ols <= 16) EMU_OLS(16)
       else if (p.n_ols <= 24) EMU_OLS(24)
