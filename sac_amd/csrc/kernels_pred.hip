@@ -81,45 +81,54 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
 }
 
 // ------------------------------------------------------------------ stage 2: cascade
-// the middle class is capped at 256 VGPRs (a few chain temporaries go to scratch): two workgroups
-// per CU instead of one, +49 % saturated throughput for -15 % single-item speed
-template <class C>
-__global__ __launch_bounds__(256, (C::total > 15 && C::total <= 30) ? 2 : 1) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, double *pbuf, LmsRingCap rc) {
+// Register-capacity classes of the cascade: taps up to (2048,1024,512,256) / (4096,..) on 256 lanes,
+// (8192,4096,2048,1024) on 512 lanes with the middle class's slot counts.  The two larger ones are
+// capped at 256 VGPRs (a few chain temporaries go to scratch): two 4-wave workgroups resp. one
+// 8-wave workgroup per CU.
+using LmsA = LmsClass<8, 4, 2, 1>;
+using LmsB = LmsClass<16, 8, 4, 2>;
+template <int CLS> struct LmsCfg;
+template <> struct LmsCfg<0> { using C = LmsA; static constexpr int NL = 256, MINB = 1; };
+template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<2> { using C = LmsB; static constexpr int NL = 512, MINB = 1; };
+
+template <int CLS>
+__global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, double *pbuf, LmsRingCap rc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NL = LmsCfg<CLS>::NL;
+  using C = typename LmsCfg<CLS>::C;
   const WorkItem &it = items[idx[blockIdx.x]];
   const ChanParam p = it.p;
   double sp[4];
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
-  ExecDev<256> ex;
-  lms_stage<ExecDev<256>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem, rc.c, v.prof);
+  ExecDev<NL> ex;
+  lms_stage<ExecDev<NL>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem, rc.c, v.prof);
 }
 
-template <class C>
+template <int CLS>
 static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, LmsRingCap rc, PcmView v, const double *d_tab, double *d_p) {
+  constexpr int NL = LmsCfg<CLS>::NL;
+  using C = typename LmsCfg<CLS>::C;
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void *)k_lms<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LmsLds<256, C>::bytes()); once = true; }
-  const size_t bytes = LmsLds<256, C>::bytes(rc.c);
-  hipLaunchKernelGGL((k_lms<C>), dim3(count), dim3(256), bytes, s, d_items, d_idx, v, d_tab, d_p, rc);
+  if (!once) { (void)hipFuncSetAttribute((const void *)k_lms<CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LmsLds<NL, C>::bytes()); once = true; }
+  const size_t bytes = LmsLds<NL, C>::bytes(rc.c);
+  hipLaunchKernelGGL((k_lms<CLS>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_tab, d_p, rc);
 }
-
-using LmsA = LmsClass<8, 4, 2, 1>;
-using LmsB = LmsClass<16, 8, 4, 2>;
-using LmsC = LmsClass<32, 16, 8, 4>;
 
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
-  return lms_class == 0 ? LmsLds<256, LmsA>::bytes(rc.c) : lms_class == 1 ? LmsLds<256, LmsB>::bytes(rc.c) : LmsLds<256, LmsC>::bytes(rc.c);
+  return lms_class == 0 ? LmsLds<256, LmsA>::bytes(rc.c) : lms_class == 1 ? LmsLds<256, LmsB>::bytes(rc.c) : LmsLds<512, LmsB>::bytes(rc.c);
 }
 
-// one wave of the workgroup per SIMD; 512 registers per SIMD lane: 237 / 256 (capped) / 506 per class
+// register-file bound on resident workgroups per CU (237 / 256 / 256 registers, 4 / 4 / 8 waves)
 int lms_max_wg_per_cu(int lms_class) { return lms_class == 2 ? 1 : 2; }
 
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, double *d_p) {
   if (count <= 0) return;
-  if (lms_class == 0) launch_lms_c<LmsA>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
-  else if (lms_class == 1) launch_lms_c<LmsB>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
-  else launch_lms_c<LmsC>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
+  if (lms_class == 0) launch_lms_c<0>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
+  else if (lms_class == 1) launch_lms_c<1>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
+  else launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
 }
 
 // ------------------------------------------------------------------ stage 3: bias + residual

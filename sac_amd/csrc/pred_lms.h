@@ -30,7 +30,6 @@ struct LmsClass {
   SA_HD static constexpr int slots(int s) { return s == 0 ? C0 : s == 1 ? C1 : s == 2 ? C2 : C3; }
   SA_HD static constexpr int first(int s) { return s == 0 ? 0 : s == 1 ? C0 : s == 2 ? C0 + C1 : C0 + C1 + C2; }
 };
-constexpr int kLmsChunk = 256;   // samples staged per global<->LDS exchange (== NL)
 constexpr int kRlsMax = 10;
 
 template <int N> struct DArr { double v[N]; };
@@ -63,8 +62,8 @@ struct LmsLds {
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
     for (int s = 0; s < 4; s++) d += (size_t)ringcap[s];
-    d += 2 * (NL / 64) * 8 + 8 + 2 * kLmsChunk + 3 * kRlsMax + 8 + 10 + 8 + kLibmLdsDoubles;
-    return d * sizeof(double) + kLmsChunk * sizeof(int) + 16;
+    d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + 8 + 10 + 8 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
+    return d * sizeof(double) + NL * sizeof(int) + 16;
   }
   SA_HD static size_t bytes() {
     const int full[4] = {C::slots(0) * NL + 1, C::slots(1) * NL + 1, C::slots(2) * NL + 1, C::slots(3) * NL + 1};
@@ -75,7 +74,7 @@ struct LmsLds {
     for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ringcap[s]; }
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 8;
-    pin = d; d += kLmsChunk; pout = d; d += kLmsChunk;
+    pin = d; d += NL; pout = d; d += NL;
     rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
     pv = d; d += 8; exwm = d; d += 10; cst = d; d += 8;
     libm = d; d += kLibmLdsDoubles;
@@ -90,7 +89,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
                      unsigned long long *prof = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
-  static_assert(kLmsChunk == NL, "chunk staging assumes one element per lane");
+  constexpr int kLmsChunk = NL;   // samples staged per global<->LDS exchange: one element per lane
   LmsLds<NL, C> L;
   L.carve(lds_base, ringcap);
 

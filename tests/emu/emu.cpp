@@ -14,12 +14,12 @@
 using namespace sacamd;
 #define API extern "C" __attribute__((visibility("default")))
 
-template <class C>
+template <class C, int NL = 256>
 static void run_lms(const ChanParam &p, const double *sp, const double *tab, const int *self, int n, double *pio) {
-  std::vector<char> lds(LmsLds<256, C>::bytes());
-  ExecEmu<256> ex;
+  std::vector<char> lds(LmsLds<NL, C>::bytes());
+  ExecEmu<NL> ex;
   const int rc[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};   // tight rings, as the host sizes them
-  lms_stage<ExecEmu<256>, C>(ex, p, sp, tab, self, n, pio, lds.data(), rc);
+  lms_stage<ExecEmu<NL>, C>(ex, p, sp, tab, self, n, pio, lds.data(), rc);
 }
 
 // samples planar [nch][total] mean-removed; stats [nch][3] = {min,max,mean}
@@ -61,7 +61,7 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     const int *vn = p.vn;
     if (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) run_lms<LmsClass<8, 4, 2, 1>>(p, sp, tab.data(), self, n, ps);
     else if (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<16, 8, 4, 2>>(p, sp, tab.data(), self, n, ps);
-    else run_lms<LmsClass<32, 16, 8, 4>>(p, sp, tab.data(), self, n, ps);
+    else run_lms<LmsClass<16, 8, 4, 2>, 512>(p, sp, tab.data(), self, n, ps);   // as the launcher: 512 lanes
     std::vector<double> tables(kBiasSlabDoubles);
     bias_stage(p, self, n, ps, stats[3 * ch_self + 2], err + (size_t)ch_self * n, pred ? pred + (size_t)ch_self * n : nullptr, tables.data());
   }

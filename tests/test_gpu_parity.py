@@ -149,8 +149,15 @@ def test_random_profiles_residuals(api, orc):
     ctx = api.Context(2, FRAMESIZE, 1)
     ctx.upload_i32([raw], FRAMESIZE)
     ctx.analyse(api.make_cfg("normal"))
-    for i in range(4):
-        g = rand_profile(P, rng, cap=False, scale=1.0 + i)
+    profiles = [rand_profile(P, rng, cap=False, scale=1.0 + i) for i in range(4)]
+    for taps, ols in (((8192, 4096, 2048, 1024), (32, 32, 32, 24, 8)),      # largest cascade class (512 lanes), OLS 64 / 64
+                      ((4096, 2048, 1024, 512), (32, 9, 32, 12, 5)),        # middle cascade class, OLS 41 / 49 (panel kernels)
+                      ((300, 40, 8, 2), (32, 32, 32, 32, 32))):             # OLS 64 / 96 (two-wave generic path)
+        g = P[:, 2].copy()
+        g[28], g[29], g[30], g[37] = taps; g[31], g[32], g[33], g[38] = taps
+        g[24], g[9], g[25], g[26], g[27] = ols
+        profiles.append(g.astype(np.float32))
+    for g in profiles:
         want, _ = orc.predict_frame(smp, stats, g, 0, 900, 1)
         _, _, err, _ = ctx.debug_predict(0, g, 0, 900, 1)
         assert np.array_equal(err, want)
