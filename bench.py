@@ -236,7 +236,7 @@ def main():
         def kname(kind, cls):
             if kind == "ols":
                 return f"k_ols<{64 if cls < 3 else (256 if cls < 7 else 128)},{ols_nmax[cls]}>"
-            return "k_lms<LmsClass<%s>>" % ("8,4,2,1", "16,8,4,2", "32,16,8,4")[cls]
+            return f"k_lms<{cls}>"
         cands = {}
         for (kind, cls), (ms, launches, isteps) in ct.items():
             cands[kname(kind, cls)] = (ms, launches, STAGE_BYTES[kind] * isteps)
