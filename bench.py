@@ -263,6 +263,8 @@ def main():
             "kernel_ms": {k: round(v["ms"], 2) for k, v in kt.items()},
             "kernel_launches": {k: v["launches"] for k, v in kt.items()},
             "kernel_instances_ms": {k: round(v[0], 2) for k, v in sorted(cands.items())},
+            "kernel_instances_launches": {k: int(v[1]) for k, v in sorted(cands.items())},
+            "kernel_instances_algorithmic_MB": {k: round(v[2] / 1e6, 1) for k, v in sorted(cands.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(nthreads=args.dds_n)
