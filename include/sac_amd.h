@@ -113,6 +113,20 @@ int sacamd_get_encoded(sacamd_ctx *ctx, int frame, int ch, uint8_t *out, int cap
 int sacamd_encode_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles_io, uint8_t *out,
                          long long cap, long long *rec_off /* [nframes+1] */);
 
+/* ---- (7) adaptive sub-frame split -------------------------------------------------------------
+ * Replaces: Codec::Analyse + AnalyseSparse + PushState (libsac/libsac.cpp:696-780) with SparsePCM::Analyse
+ * (libsac/sparse.h:31-96): one read of samples_read samples per channel (planar int32, host memory, un-centred)
+ * is cut into blocks of blocksamples; a block is "sparse" when the mean over channels of
+ * sum|val| / sum|rank(val)| exceeds 1.35; runs of equal state become sub-frames, a run shorter than
+ * min_frame_length is appended to its predecessor.  The reference calls it with blocksamples ==
+ * min_frame_length == 3 * rate (libsac.cpp:812-816).  The block sums are computed on the GPU. */
+typedef struct sacamd_subframe { int start, length, state; } sacamd_subframe;
+int sacamd_plan_subframes(sacamd_ctx *ctx, const int32_t *pcm_planar, long long ch_stride, int nch, int samples_read,
+                          int blocksamples, int min_frame_length, sacamd_subframe *out, int cap, int *count);
+/* the PushState state machine alone (host only, no device work): block_state / block_len per block */
+int sacamd_subframes_from_states(const int *block_state, const int *block_len, int nblocks, int min_frame_length,
+                                 sacamd_subframe *out, int cap, int *count);
+
 /* ---- parity taps (tests) -------------------------------------------------------------------
  * Per-stage streams of one frame for one profile: p_lpc, p_lpc+p_lms (file-channel order),
  * residual and pred, over window [start,start+n).  == oracle predict_trace. */

@@ -28,6 +28,11 @@
 #include "libsac/cost.h"
 #include "libsac/vle.h"
 #include "libsac/map.h"
+#include <numeric>
+#include <limits>
+#include <stdexcept>
+#include "common/utils.h"
+#include "libsac/sparse.h"
 #include "opt/opt.h"
 #include "opt/ssc.h"
 
@@ -559,6 +564,29 @@ API int ref_decode_frame(const uint8_t *rec, int len, int nch, int framesize, in
   if (coefs_out)
     for (int i = 0; i < 58; i++) coefs_out[i] = fc.base_profile.coefs[i].vdef;
   return n;
+}
+
+
+// ---------------------------------------------------------------- adaptive sub-frame split
+// Genuine Codec::Analyse (+ AnalyseSparse / PushState, SparsePCM) on one read of `samples_read`
+// samples per channel.  out: triples {start, length, state}.
+API int ref_plan_subframes(int nch, int samples_read, const int32_t *pcm, long long ch_stride, int blocksamples,
+                           int min_frame_length, int *out, int cap) {
+  FrameCoder::tsac_cfg cfg = make_cfg(4, 1, 1);
+  cfg.verbose_level = 0;
+  Codec codec(cfg);
+  std::vector<std::vector<int32_t>> samples(nch, std::vector<int32_t>(samples_read));
+  for (int ch = 0; ch < nch; ch++) std::copy_n(pcm + (size_t)ch * ch_stride, samples_read, samples[ch].begin());
+  auto sf = codec.Analyse(samples, blocksamples, min_frame_length, samples_read);
+  int n = 0;
+  for (auto &f : sf) { if (n < cap) { out[3 * n] = f.start; out[3 * n + 1] = f.length; out[3 * n + 2] = f.state; } n++; }
+  return n;
+}
+// SparsePCM::Analyse on one buffer -> {fraction_used, fraction_cost}
+API void ref_sparse_cost(const int32_t *buf, int n, double *out2) {
+  SparsePCM sp;
+  sp.Analyse(std::span<const int32_t>(buf, (size_t)n));
+  out2[0] = sp.fraction_used; out2[1] = sp.fraction_cost;
 }
 
 API int ref_abi_version() { return 1; }

@@ -1269,6 +1269,70 @@ API int orc_mapencode(const uint8_t *usedl, const uint8_t *usedh, uint8_t *out, 
   std::memcpy(out, r.out.data(), len);
   return len;
 }
+
+// ---------------------------------------------------------------- adaptive sub-frame split
+// SparsePCM::Analyse (libsac/sparse.h:31-73): fraction of the value range [min,max] in use and
+// the ratio sum|val| / sum|rank(val)| where rank counts only used values between 0 and val
+// (val2rank_fast, sparse.h:77-96, with p = 0).
+static void sparse_cost(const int32_t *buf, int n, double *used_pct, double *cost) {
+  *used_pct = 0.0; *cost = 0.0;
+  if (n <= 0) return;
+  int32_t mn = buf[0], mx = buf[0];
+  for (int i = 0; i < n; i++) { if (buf[i] > mx) mx = buf[i]; if (buf[i] < mn) mn = buf[i]; }
+  const int N = mx - mn + 1;
+  std::vector<int> used(N, 0), prefix(N + 1, 0);
+  for (int i = 0; i < n; i++) used[buf[i] - mn] = 1;
+  for (int i = 0; i < N; i++) prefix[i + 1] = prefix[i] + used[i];
+  *used_pct = (prefix[N] / static_cast<double>(N)) * 100.;
+  double sum0 = 0, sum1 = 0;
+  const int pidx = 0 - mn;
+  for (int i = 0; i < n; i++) {
+    const int32_t v = buf[i];
+    int r = 0;
+    if (v > 0) r = prefix[v - mn + 1] - prefix[std::min(std::max(pidx + 1, 0), N)];
+    else if (v < 0) r = prefix[v - mn] - prefix[std::min(std::max(pidx, 0), N)];
+    sum0 += std::fabs((double)v);
+    sum1 += std::fabs((double)r);
+  }
+  *cost = sum1 > 0 ? sum0 / sum1 : 0;
+}
+
+// Codec::Analyse + PushState (libsac/libsac.cpp:705-780): blocks of `blocksamples`, state = mean over
+// channels of the sparse cost > 1.35; runs of equal state form a sub-frame, a run shorter than
+// min_frame_length is appended to the previous sub-frame (if there is one).
+struct SubFrame { int state, start, length; };
+static void push_state(std::vector<SubFrame> &sf, SubFrame &cur, int min_len, int block_state, int samples_block) {
+  if (block_state == cur.state) cur.length += samples_block;
+  else {
+    if (cur.length < min_len && !sf.empty()) sf.back().length += cur.length;   // extend (cur is left as it is: libsac.cpp:711-714)
+    else {
+      sf.push_back(cur);
+      if (samples_block) { cur.state = block_state; cur.start += cur.length; cur.length = samples_block; }
+    }
+  }
+}
+API int orc_plan_subframes(int nch, int samples_read, const int32_t *pcm, long long ch_stride, int blocksamples,
+                           int min_frame_length, int *out, int cap) {
+  std::vector<SubFrame> sf;
+  SubFrame cur{-1, 0, 0};
+  int done = 0, nblock = 0;
+  while (done < samples_read) {
+    const int nb = std::min(blocksamples, samples_read - done);
+    double avg_cost = 0;
+    for (int ch = 0; ch < nch; ch++) { double u, c; sparse_cost(pcm + (size_t)ch * ch_stride + done, nb, &u, &c); avg_cost += c; }
+    avg_cost /= (double)nch;
+    const int st = avg_cost > 1.35;
+    if (nblock == 0) { cur.state = st; cur.length = nb; cur.start = 0; }
+    else push_state(sf, cur, min_frame_length, st, nb);
+    done += nb; nblock++;
+  }
+  if (cur.length) push_state(sf, cur, min_frame_length, -1, 0);
+  int n = 0;
+  for (auto &f : sf) { if (n < cap) { out[3 * n] = f.start; out[3 * n + 1] = f.length; out[3 * n + 2] = f.state; } n++; }
+  return n;
+}
+API void orc_sparse_cost(const int32_t *buf, int n, double *out2) { sparse_cost(buf, n, &out2[0], &out2[1]); }
+
 API void orc_analyse(const int32_t *raw, int n, int32_t *out) { analyse(raw, n, &out[0], &out[1], &out[2]); }
 API void orc_rng(int n, const int *kinds, const double *args, double *out) {
   DDS d;

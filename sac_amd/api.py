@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "sacamd_frames_attach_s16_device", "sacamd_analyse", "sacamd_get_stats", "sacamd_evaluate",
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
-    "sacamd_kernel_times", "sacamd_class_times", "sacamd_debug_ols_profile", "sacamd_abi_version",
+    "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_debug_ols_profile", "sacamd_abi_version",
 ]
 
 
@@ -83,6 +83,22 @@ def default_profile() -> np.ndarray:
     out = np.zeros((3, NUM_COEFS), np.float32)
     lib.sacamd_default_profile(_vp(out[0]), _vp(out[1]), _vp(out[2]))
     return np.ascontiguousarray(out.T)
+
+
+class SubFrame(ctypes.Structure):
+    _fields_ = [("start", c_int), ("length", c_int), ("state", c_int)]
+
+
+def subframes_from_states(block_state, block_len, min_frame_length):
+    """Codec::PushState state machine (host only) -> [(start, length, state)]."""
+    lib = load_library()
+    st = np.ascontiguousarray(block_state, np.int32); bl = np.ascontiguousarray(block_len, np.int32)
+    out = (SubFrame * max(1, len(st)))()
+    cnt = c_int(0)
+    rc = lib.sacamd_subframes_from_states(_vp(st), _vp(bl), len(st), int(min_frame_length), out, len(out), byref(cnt))
+    if rc != 0:
+        raise SacAmdError(f"sacamd_subframes_from_states failed ({rc})")
+    return [(out[i].start, out[i].length, out[i].state) for i in range(cnt.value)]
 
 
 class Context:
@@ -191,6 +207,53 @@ class Context:
         self._chk(self.lib.sacamd_encode_frames(self.h, byref(cfg), _vp(prof), _vp(out), c_longlong(cap), _vp(off)))
         recs = [out[off[f]: off[f + 1]].tobytes() for f in range(self.nframes)]
         return recs, prof
+
+    # ---- adaptive sub-frame split + batch file driver (Codec::Analyse / Codec::EncodeFile's frame loop)
+    def plan_subframes(self, pcm, blocksamples, min_frame_length, samples_read=None):
+        """pcm [nch, n] int32 (raw, un-centred) -> [(start, length, state)] as Codec::Analyse cuts one read."""
+        pcm = np.ascontiguousarray(pcm, np.int32)
+        nch, n = pcm.shape
+        sr = n if samples_read is None else int(samples_read)
+        out = (SubFrame * 64)()
+        cnt = c_int(0)
+        self._chk(self.lib.sacamd_plan_subframes(self.h, _vp(pcm), c_longlong(n), nch, sr, int(blocksamples), int(min_frame_length),
+                                                 out, 64, byref(cnt)))
+        return [(out[i].start, out[i].length, out[i].state) for i in range(cnt.value)]
+
+    def plan_file(self, pcm, rate, max_framelen=20, adapt_block=True):
+        """Frame list of one file as Codec::EncodeFile produces it (libsac.cpp:782-829): reads of
+        max_framelen*rate samples, each cut into sub-frames (3 s blocks) -> [(start, length)] in file order."""
+        pcm = np.asarray(pcm)
+        total = pcm.shape[1]
+        maxfs = int(max_framelen) * int(rate)
+        frames = []
+        pos = 0
+        while pos < total:
+            n = min(maxfs, total - pos)
+            if adapt_block:
+                subs = self.plan_subframes(pcm[:, pos: pos + n], 3 * rate, 3 * rate)
+            else:
+                subs = [(0, n, 0)]
+            frames += [(pos + s, ln) for s, ln, _ in subs]
+            pos += n
+        return frames
+
+    def encode_pcm_files(self, files, rate, cfg: Cfg, max_framelen=20, adapt_block=True):
+        """Batch driver: every frame of every file in one staged batch (frames are independent with
+        cfg.reset=1).  files: list of int [nch, n] arrays.  Returns per file the list of frame records."""
+        plans = [self.plan_file(f, rate, max_framelen, adapt_block) for f in files]
+        frames, owner = [], []
+        for fi, (f, plan) in enumerate(zip(files, plans)):
+            for s, ln in plan:
+                frames.append(np.ascontiguousarray(np.asarray(f)[:, s: s + ln], np.int32)); owner.append(fi)
+        out = [[] for _ in files]
+        for b0 in range(0, len(frames), self.max_frames):
+            chunk = frames[b0: b0 + self.max_frames]
+            self.upload_i32(chunk, int(max_framelen) * int(rate))
+            recs, _ = self.encode_frames(cfg)
+            for k, r in enumerate(recs):
+                out[owner[b0 + k]].append(r)
+        return out, plans
 
     # ---- parity taps
     def debug_predict(self, frame, coefs, start, n, optimize, optk=4):

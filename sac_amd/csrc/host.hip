@@ -96,7 +96,7 @@ struct sacamd_ctx {
   bool analysed = false, final_done = false, encoded = false;
   std::vector<int> nsamp;
   long long ch_stride = 0, frame_stride = 0;
-  DevBuf<int> d_pcm, d_nsamp, d_raw32;
+  DevBuf<int> d_pcm, d_nsamp, d_raw32, d_plan_pcm;
   DevBuf<int16_t> d_raw16;
   const int16_t *attached16 = nullptr;
   DevBuf<long long> d_frame_off;
@@ -389,7 +389,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); (void)hipStreamDestroy(c->stream); }
   for (int k = 0; k < sacamd_ctx::kSide; k++) { if (c->cls_stream[k]) (void)hipStreamDestroy(c->cls_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_raw16.release(); c->d_frame_off.release();
+  c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
   c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_cost.release();
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
@@ -661,6 +661,74 @@ API int sacamd_debug_cost(sacamd_ctx *c, int kind, const int32_t *err, int n, do
 }
 
 // debug: enable (on!=0) / read the OLS kernel's section cycle counters of the last launch
+
+// ================================================================== (7) adaptive sub-frame split
+API int sacamd_subframes_from_states(const int *block_state, const int *block_len, int nblocks, int min_frame_length,
+                                     sacamd_subframe *out, int cap, int *count) {
+  if (!block_state || !block_len || !count || nblocks < 0) return SACAMD_ERR_ARG;
+  std::vector<sacamd_subframe> sf;
+  sacamd_subframe cur{0, 0, -1};
+  // PushState (libsac.cpp:705-727): note that the "extend" branch leaves the current run untouched
+  auto push = [&](int st, int nb) {
+    if (st == cur.state) cur.length += nb;
+    else if (cur.length < min_frame_length && !sf.empty()) sf.back().length += cur.length;
+    else {
+      sf.push_back(cur);
+      if (nb) { cur.state = st; cur.start += cur.length; cur.length = nb; }
+    }
+  };
+  for (int b = 0; b < nblocks; b++) {
+    if (b == 0) { cur.state = block_state[0]; cur.length = block_len[0]; cur.start = 0; }
+    else push(block_state[b], block_len[b]);
+  }
+  if (cur.length) push(-1, 0);
+  *count = (int)sf.size();
+  for (int i = 0; i < (int)sf.size() && i < cap; i++) out[i] = sf[i];
+  return (int)sf.size() > cap && out ? SACAMD_ERR_ARG : 0;
+}
+
+API int sacamd_plan_subframes(sacamd_ctx *c, const int32_t *pcm, long long ch_stride, int nch, int samples_read,
+                              int blocksamples, int min_frame_length, sacamd_subframe *out, int cap, int *count) {
+  if (!c || !pcm || !count || nch < 1 || samples_read < 0 || blocksamples < 1) return SACAMD_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nblocks = (samples_read + blocksamples - 1) / blocksamples;
+  if (nblocks == 0) { *count = 0; return 0; }
+  // stage the read (own scratch: the staged batch of the context is left alone)
+  HIPCHK(c, c->d_plan_pcm.ensure((size_t)nch * samples_read));
+  for (int ch = 0; ch < nch; ch++)
+    HIPCHK(c, hipMemcpyAsync(c->d_plan_pcm.p + (size_t)ch * samples_read, pcm + (size_t)ch * ch_stride, sizeof(int) * (size_t)samples_read,
+                             hipMemcpyHostToDevice, c->stream));
+  std::vector<long long> off((size_t)nblocks * nch);
+  std::vector<int> nn((size_t)nblocks * nch), blen(nblocks);
+  for (int b = 0; b < nblocks; b++) {
+    blen[b] = std::min(blocksamples, samples_read - b * blocksamples);
+    for (int ch = 0; ch < nch; ch++) { off[(size_t)b * nch + ch] = (long long)ch * samples_read + (long long)b * blocksamples; nn[(size_t)b * nch + ch] = blen[b]; }
+  }
+  const int jobs = nblocks * nch;
+  HIPCHK(c, c->d_off.ensure(jobs)); HIPCHK(c, c->d_n.ensure(jobs)); HIPCHK(c, c->d_out3.ensure((size_t)jobs * 4));
+  HIPCHK(c, hipMemcpyAsync(c->d_off.p, off.data(), sizeof(long long) * jobs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_n.p, nn.data(), sizeof(int) * jobs, hipMemcpyHostToDevice, c->stream));
+  { Span sp(c, FAM_ANALYSE); launch_sparse_cost(c->stream, c->d_plan_pcm.p, c->d_off.p, c->d_n.p, jobs, c->d_out3.p); }
+  HIPCHK(c, hipGetLastError());
+  std::vector<long long> sums((size_t)jobs * 4);
+  HIPCHK(c, hipMemcpyAsync(sums.data(), c->d_out3.p, sizeof(long long) * sums.size(), hipMemcpyDeviceToHost, c->stream));
+  int r = sync_stream(c);
+  if (r) return r;
+  std::vector<int> state(nblocks);
+  for (int b = 0; b < nblocks; b++) {
+    double avg_cost = 0;
+    for (int ch = 0; ch < nch; ch++) {
+      const long long *q = &sums[((size_t)b * nch + ch) * 4];
+      if (q[3] < 0) return fail(c, SACAMD_ERR_ARG, "sub-frame analysis: value range of a block exceeds 2^17");
+      // sparse.h:52-72: both sums are exact integers in the reference's doubles
+      avg_cost += q[1] > 0 ? static_cast<double>(q[0]) / static_cast<double>(q[1]) : 0.0;
+    }
+    avg_cost /= (double)nch;
+    state[b] = avg_cost > 1.35;
+  }
+  return sacamd_subframes_from_states(state.data(), blen.data(), nblocks, min_frame_length, out, cap, count);
+}
+
 API int sacamd_class_times(sacamd_ctx *c, double *out, int reset) {
   if (!c || !out) return SACAMD_ERR_ARG;
   collect_spans(c);

@@ -34,6 +34,8 @@ void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_o
                  int *d_hist_scratch, double *d_cost);
 void launch_s2u(hipStream_t s, const int *d_err, int *d_s2u, const long long *d_off, const int *d_n, int count, int *d_maxbpn);
 size_t cost_hist_scratch_ints();
+// SparsePCM::Analyse sums per block: out4[4b..] = {sum|val|, sum|rank|, used values, range (-1: unsupported)}
+void launch_sparse_cost(hipStream_t s, const int *d_pcm, const long long *d_off, const int *d_n, int count, long long *d_out4);
 // ---- coder (kernels_coder.hip)
 struct CoderJob {
   long long off_in;     // ints into d_s2u

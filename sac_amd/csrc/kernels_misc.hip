@@ -73,6 +73,71 @@ void launch_analyse_i32(hipStream_t s, int nframes, int nch, const int *d_raw, l
   hipLaunchKernelGGL(k_analyse_i32, dim3(nframes, nch), dim3(256), 0, s, nch, d_raw, rfs, rcs, d_nsamp, zero_mean, d_pcm, fs, cs, d_stats, d_used);
 }
 
+
+// ------------------------------------------------------------------ sparse-PCM block analysis
+// SparsePCM::Analyse (libsac/sparse.h:31-73) for one block of one channel per workgroup:
+// out[4b..] = { sum |val|, sum |rank(val)|, #used values, range } with rank = number of used
+// values in (0, val] resp. [val, 0) (val2rank_fast with p = 0).  The used set is a bitmap over
+// [min, max] in LDS (16-bit material: <= 65536 values); range > kSparseMaxRange -> out[3] = -1.
+constexpr int kSparseMaxRange = 1 << 17;
+constexpr int kSparseWords = kSparseMaxRange / 32;
+__global__ __launch_bounds__(256) void k_sparse_cost(const int *pcm, const long long *off, const int *nn, long long *out) {
+  __shared__ unsigned bits[kSparseWords];
+  __shared__ int pre[kSparseWords + 1];
+  __shared__ int s_i[4];
+  __shared__ long long s_ll[4];
+  const int b = blockIdx.x;
+  const int *x = pcm + off[b];
+  const int n = nn[b];
+  long long *o = out + 4LL * b;
+  if (n <= 0) { if (threadIdx.x == 0) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; } return; }
+  int mn = 2147483647, mx = -2147483647 - 1;
+  for (int i = threadIdx.x; i < n; i += 256) { const int v = x[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+  mn = block_reduce(mn, s_i, [](int a, int c) { return a < c ? a : c; });
+  mx = block_reduce(mx, s_i, [](int a, int c) { return a > c ? a : c; });
+  const long long range = (long long)mx - mn + 1;
+  if (range > kSparseMaxRange) { if (threadIdx.x == 0) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = -1; } return; }
+  const int N = (int)range, nw = (N + 31) >> 5;
+  for (int i = threadIdx.x; i < nw; i += 256) bits[i] = 0u;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) { const int t = x[i] - mn; atomicOr(&bits[t >> 5], 1u << (t & 31)); }
+  __syncthreads();
+  // exclusive prefix of the per-word popcounts: each thread owns a contiguous run of words
+  const int per = (nw + 255) / 256, w0 = threadIdx.x * per, w1 = (w0 + per < nw) ? w0 + per : nw;
+  int loc = 0;
+  for (int w = w0; w < w1; w++) loc += __popc(bits[w]);
+  __shared__ int part[256];
+  part[threadIdx.x] = loc;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; i++) { const int t = part[i]; part[i] = run; run += t; } pre[nw] = run; }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int w = w0; w < w1; w++) { pre[w] = run; run += __popc(bits[w]); }
+  __syncthreads();
+  auto prefix = [&](int idx) {           // number of used values with index < idx, idx in [0, N]
+    const int w = idx >> 5, r = idx & 31;
+    return pre[w] + (r ? __popc(bits[w] & ((1u << r) - 1u)) : 0);
+  };
+  const int pidx = 0 - mn;
+  const int pa = prefix(pidx + 1 < 0 ? 0 : (pidx + 1 > N ? N : pidx + 1));
+  const int pb = prefix(pidx < 0 ? 0 : (pidx > N ? N : pidx));
+  long long s0 = 0, s1 = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int v = x[i];
+    int r = 0;
+    if (v > 0) r = prefix(v - mn + 1) - pa; else if (v < 0) r = prefix(v - mn) - pb;
+    s0 += v < 0 ? -(long long)v : v;
+    s1 += r < 0 ? -(long long)r : r;
+  }
+  s0 = block_reduce(s0, s_ll, [](long long a, long long c) { return a + c; });
+  s1 = block_reduce(s1, s_ll, [](long long a, long long c) { return a + c; });
+  if (threadIdx.x == 0) { o[0] = s0; o[1] = s1; o[2] = pre[nw]; o[3] = N; }
+}
+void launch_sparse_cost(hipStream_t s, const int *d_pcm, const long long *d_off, const int *d_n, int count, long long *d_out4) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_sparse_cost, dim3(count), dim3(256), 0, s, d_pcm, d_off, d_n, d_out4);
+}
+
 // ------------------------------------------------------------------ cost functions (cost.h)
 constexpr int kHistGlobal = 1 << 18;   // residual range of 16-bit material: < 2^17+1
 size_t cost_hist_scratch_ints() { return kHistGlobal; }

@@ -19,6 +19,21 @@ from golden_cases import FRAMESIZE, frame_cases, trace_cases  # noqa: E402
 from oracle_api import Checker, center_frame  # noqa: E402
 
 
+def main_subframes():
+    """tests/golden/subframes_golden.npz: Codec::Analyse sub-frame lists and SparsePCM costs."""
+    from golden_cases import subframe_cases
+    R = Checker("ref")
+    out = {}
+    for name, (pcm, blk, min_len) in subframe_cases().items():
+        out[f"{name}/pcm"] = pcm.astype(np.int16)
+        out[f"{name}/args"] = np.array([blk, min_len], np.int32)
+        out[f"{name}/subframes"] = np.array(R.plan_subframes(pcm, blk, min_len), np.int32).reshape(-1, 3)
+        out[f"{name}/cost_block0"] = np.array([R.sparse_cost(pcm[ch, :blk]) for ch in range(pcm.shape[0])])
+    path = os.path.join(HERE, "subframes_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
     R = Checker("ref")
     out = {}
@@ -96,4 +111,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--subframes" in sys.argv:
+        main_subframes()
+    else:
+        main()

@@ -57,3 +57,24 @@ def trace_cases(P):
     c["tr_s16_maxols"] = (synth_pcm(900, 2, 25, RATE), g, 1, 0, 900)
     c["tr_m8_default"] = (synth_pcm(1500, 1, 26, RATE, bits=8), P[:, 2].copy(), 0, 0, 1500)
     return c
+
+
+def subframe_cases():
+    """name -> (pcm [nch,n] int32 raw, blocksamples, min_frame_length): material whose 3-"second"
+    blocks alternate between dense and sparse (quantised) PCM, for Codec::Analyse / PushState."""
+    rate = 1000
+    blk = 3 * rate
+    rng = np.random.default_rng(17)
+    c = {}
+    specs = [("dense_only", [0, 0, 0], 1, 500, blk), ("sparse_tail", [0, 0, 0, 0, 16, 16], 2, 1945, blk),
+             ("alternating", [16, 0, 4, 4, 0, 0, 0], 2, 20, blk), ("short_last_block", [0, 16, 0, 0], 1, 7, blk),
+             ("min_two_blocks", [0, 4, 0, 0, 16, 0, 4, 4], 2, 1200, 2 * blk), ("all_sparse", [8, 8], 1, 0, blk)]
+    for name, pattern, nch, tail, min_len in specs:
+        n = len(pattern) * blk + tail
+        x = synth_pcm(n, nch, int(rng.integers(1, 1 << 20)), rate) >> 5     # ~1000 distinct values: 3000-sample blocks are dense
+        for i, q in enumerate(pattern + [pattern[-1]]):
+            a, b = i * blk, min((i + 1) * blk, n)
+            if q and a < b:
+                x[:, a:b] = (x[:, a:b] // q) * q
+        c[name] = (x.astype(np.int32), blk, min_len)
+    return c

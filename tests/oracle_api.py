@@ -170,6 +170,24 @@ class Checker:
         self.f("analyse")(_vp(raw), raw.size, _vp(out))
         return out  # mean, min, max
 
+    # ---- adaptive sub-frame split (Codec::Analyse)
+    def plan_subframes(self, pcm, blocksamples, min_frame_length, samples_read=None):
+        """pcm [nch, n] int32 (raw) -> list of (start, length, state)."""
+        pcm = np.ascontiguousarray(pcm, np.int32)
+        nch, n = pcm.shape
+        sr = n if samples_read is None else samples_read
+        out = np.zeros(3 * 64, np.int32)
+        fn = self.f("plan_subframes"); fn.restype = ctypes.c_int
+        cnt = fn(nch, sr, _vp(pcm), ctypes.c_longlong(n), blocksamples, min_frame_length, _vp(out), 64)
+        assert 0 <= cnt <= 64
+        return [tuple(int(x) for x in out[3 * i: 3 * i + 3]) for i in range(cnt)]
+
+    def sparse_cost(self, buf):
+        buf = np.ascontiguousarray(buf, np.int32)
+        out = np.zeros(2)
+        self.f("sparse_cost")(_vp(buf), buf.size, _vp(out))
+        return float(out[0]), float(out[1])
+
     # ---- search helpers
     def rng(self, kinds, args=None):
         kinds = np.ascontiguousarray(kinds, np.int32)

@@ -131,3 +131,18 @@ def test_record_gather_two_ranks_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "GATHER_OK" in r.stdout
+
+
+def test_subframe_state_machine_host(orc):
+    """sacamd_subframes_from_states (host part of sacamd_plan_subframes) against the oracle's planner,
+    with the block states taken from the oracle's SparsePCM cost."""
+    import sac_amd.api as api
+    from golden_cases import subframe_cases
+    for name, (pcm, blk, min_len) in subframe_cases().items():
+        n = pcm.shape[1]
+        lens = [min(blk, n - a) for a in range(0, n, blk)]
+        states = []
+        for b, ln in enumerate(lens):
+            c = np.mean([orc.sparse_cost(pcm[ch, b * blk: b * blk + ln])[1] for ch in range(pcm.shape[0])])
+            states.append(int(c > 1.35))
+        assert api.subframes_from_states(states, lens, min_len) == orc.plan_subframes(pcm, blk, min_len), name

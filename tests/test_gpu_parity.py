@@ -191,3 +191,44 @@ def test_genuine_reference_decoder_reads_gpu_records(api, ref, golden):
         ctx.close()
         dec, _ = ref.decode_frame(recs[0], raw.shape[0], FRAMESIZE)
         assert np.array_equal(dec, raw)
+
+
+def test_subframe_plan_gpu_vs_oracle(api, orc):
+    """sacamd_plan_subframes (block sums on the GPU) == Codec::Analyse for the golden patterns."""
+    import os
+    from golden_cases import subframe_cases
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subframes_golden.npz"))
+    ctx = api.Context(2, FRAMESIZE, 4)
+    for name, (pcm, blk, min_len) in subframe_cases().items():
+        want = [tuple(int(v) for v in row) for row in g[f"{name}/subframes"]]
+        assert ctx.plan_subframes(pcm, blk, min_len) == want, name
+    # 44.1 kHz-sized blocks (132300 samples, full 16-bit range)
+    raw = synth_pcm(3 * 132300 + 777, 2, 4242, 44100)
+    raw[:, 132300: 2 * 132300] = (raw[:, 132300: 2 * 132300] // 8) * 8
+    assert ctx.plan_subframes(raw, 132300, 132300) == orc.plan_subframes(raw, 132300, 132300)
+    ctx.close()
+
+
+def test_batch_file_driver_vs_oracle(api, orc):
+    """Frames of several files (reads of max_framelen s, adaptive sub-frame split) encoded as one GPU
+    batch == the oracle encoding each reference sub-frame on its own (Codec::EncodeFile's frame loop)."""
+    rate = RATE
+    files = [synth_pcm(int(2.4 * 3 * rate), 2, 71, rate) >> 3, synth_pcm(7 * rate + 123, 2, 72, rate) >> 3]
+    files[0][:, 3 * rate: 6 * rate] = (files[0][:, 3 * rate: 6 * rate] // 16) * 16      # a sparse 3 s block
+    max_framelen = 6                                                                   # reads of 6 s -> several reads per file
+    cfg = api.make_cfg("normal")
+    ctx = api.Context(2, max_framelen * rate, 16)
+    recs, plans = ctx.encode_pcm_files(files, rate, cfg, max_framelen=max_framelen)
+    ctx.close()
+    for f, plan, rr in zip(files, plans, recs):
+        # the oracle's frame list for the same file
+        want_plan, pos = [], 0
+        while pos < f.shape[1]:
+            n = min(max_framelen * rate, f.shape[1] - pos)
+            want_plan += [(pos + s, ln) for s, ln, _ in orc.plan_subframes(f[:, pos: pos + n], 3 * rate, 3 * rate)]
+            pos += n
+        assert plan == want_plan
+        assert len(plan) >= 2
+        for (s, ln), rec in zip(plan, rr):
+            want = orc.encode_frame(f[:, s: s + ln], frame_cfg("normal"), max_framelen * rate)["record"]
+            assert rec == want

@@ -109,3 +109,21 @@ def test_analyse(orc):
     assert orc.analyse(x).tolist() == [20, -7, 100]  # floor(104/5)=20
     x = np.array([-5, -6], np.int32)
     assert orc.analyse(x).tolist() == [-6, -6, -5]  # floor(-5.5)
+
+
+# ---- adaptive sub-frame split (Codec::Analyse / PushState / SparsePCM), SURVEY section 8(f) rank 1
+def _subgolden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subframes_golden.npz"))
+
+
+@pytest.mark.parametrize("name", ["dense_only", "sparse_tail", "alternating", "short_last_block", "min_two_blocks", "all_sparse"])
+def test_subframe_plan_matches_reference(orc, name):
+    g = _subgolden()
+    pcm = g[f"{name}/pcm"].astype(np.int32)
+    blk, min_len = (int(v) for v in g[f"{name}/args"])
+    want = [tuple(int(v) for v in row) for row in g[f"{name}/subframes"]]
+    assert orc.plan_subframes(pcm, blk, min_len) == want
+    for ch in range(pcm.shape[0]):
+        used, cost = orc.sparse_cost(pcm[ch, :blk])
+        assert (used, cost) == tuple(g[f"{name}/cost_block0"][ch])        # bit-exact doubles

@@ -79,3 +79,21 @@ def test_warm_start_profile_chain(orc, ref):
         assert a["record"] == b["record"]
         pa, pb = a["profile"], b["profile"]
         assert np.array_equal(pa, pb)
+
+
+def test_subframe_plan_vs_ref(orc, ref):
+    """Codec::Analyse on random dense/sparse block patterns, incl. min_frame_length > block."""
+    from sac_amd.synth import synth_pcm
+    rate = 2000; blk = 3 * rate
+    rng = np.random.default_rng(3)
+    for t in range(10):
+        pat = [int(rng.choice([0, 0, 4, 16])) for _ in range(int(rng.integers(1, 8)))]
+        n = len(pat) * blk + int(rng.integers(0, blk))
+        x = synth_pcm(n, int(rng.integers(1, 3)), 100 + t, rate) >> 4
+        for i, q in enumerate(pat + [pat[-1]]):
+            a, b = i * blk, min((i + 1) * blk, n)
+            if q and a < b:
+                x[:, a:b] = (x[:, a:b] // q) * q
+        for min_len in (blk, 2 * blk):
+            assert orc.plan_subframes(x, blk, min_len) == ref.plan_subframes(x, blk, min_len)
+        assert orc.sparse_cost(x[0, :blk]) == ref.sparse_cost(x[0, :blk])
