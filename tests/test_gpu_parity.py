@@ -235,13 +235,15 @@ def test_batch_file_driver_vs_oracle(api, orc):
 
 
 def test_edge_frames_ragged_batch_vs_oracle(api, orc):
-    """One ragged batch of edge-case frames == the oracle frame by frame: 1- and 2-sample frames,
-    lengths around the 64-sample coder chunk, full-scale square wave (-32768 / 32767), a constant
+    """One ragged batch of edge-case frames == the oracle frame by frame: 8- and 9-sample frames (the
+    shortest stereo frames the reference can encode: its channel loop never terminates when a frame
+    is shorter than nS1 = 8, libsac.cpp:128-140), lengths around the 64-sample coder chunk, full-scale square wave (-32768 / 32767), a constant
     (DC) frame, full-range white noise, and a frame with a silent tail."""
     rng = np.random.default_rng(77)
     sq = np.where((np.arange(700) // 7) % 2 == 0, 32767, -32768).astype(np.int32)
     tail = synth_pcm(900, 2, 55, RATE); tail[:, 500:] = 0
-    frames = [synth_pcm(1, 2, 50, RATE), synth_pcm(2, 2, 51, RATE), synth_pcm(63, 2, 52, RATE), synth_pcm(65, 2, 53, RATE),
+    base = synth_pcm(400, 2, 50, RATE)                    # (the generator needs a few hundred samples: slice it)
+    frames = [base[:, 100:108].copy(), base[:, 200:209].copy(), base[:, :63].copy(), base[:, 300:365].copy(),
               np.stack([sq, -sq - 1]), np.full((2, 300), 12345, np.int32),
               rng.integers(-32768, 32768, size=(2, 1200)).astype(np.int32), tail]
     ctx = api.Context(2, FRAMESIZE, len(frames))
