@@ -191,6 +191,7 @@ constexpr int kOlsPad = 8;
 
 // rows ip = IP .. NMAX-1 of the end-anchored back-substitution (template recursion: the register
 // array wr is only ever indexed by compile-time constants)
+constexpr int kOlsBwdChunk = 16;
 template <int NMAX, int S, int IP>
 struct OlsBwdRows {
   static SA_HD __attribute__((always_inline)) void run(int no, const double *lds0, const double *lb, const double *zb, double *wb, double (&wr)[NMAX]) {
@@ -202,8 +203,19 @@ struct OlsBwdRows {
       int rowo = (int)(lb - lds0) + (NMAX - 1 - IP) * S;   // whole offset from the start of LDS: nothing left to fold into immediates
       SA_OPAQUE_INT(rowo);
       const double *rowp = lds0 + rowo;
+      // the row's L elements are requested kOlsBwdChunk at a time, one chunk ahead of the chain
+      constexpr int CH = kOlsBwdChunk;
+      constexpr int NCH = (IP + CH - 1) / CH;
+      double buf[2][CH];
 #pragma unroll
-      for (int kp = IP - 1; kp >= 0; kp--) s_ = fma(-rowp[NMAX - 1 - kp], wr[kp], s_);
+      for (int q = 0; q < CH; q++) if (q < IP) buf[0][q] = rowp[NMAX - 1 - (IP - 1 - q)];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+#pragma unroll
+        for (int q = 0; q < CH; q++) if ((c + 1) * CH + q < IP) buf[(c + 1) & 1][q] = rowp[NMAX - 1 - (IP - 1 - ((c + 1) * CH + q))];
+#pragma unroll
+        for (int q = 0; q < CH; q++) if (c * CH + q < IP) s_ = fma(-buf[c & 1][q], wr[IP - 1 - (c * CH + q)], s_);
+      }
       wr[IP] = s_;
       wb[NMAX - 1 - IP] = s_;
       OlsBwdRows<NMAX, S, IP + 1>::run(no, lds0, lb, zb, wb, wr);
