@@ -223,6 +223,21 @@ struct OlsBwdRows {
   }
 };
 
+// second half of slmath::dot (common/math.h:130-161) once lanes 0..7 hold its eight accumulators:
+// s_c + t_c, ((s0+s1)+s2)+s3, then the < 8 tail (transform_reduce order)
+template <class E, class R>
+SA_HD double ols_dot_finish(E &ex, const R &dacc, const double *x, const double *y, int n) {
+  double total = 0.0;
+  const int nb = n & ~7;
+  if (nb) {
+    const double s0 = ex.lane_bcast(dacc, 0) + ex.lane_bcast(dacc, 4), s1 = ex.lane_bcast(dacc, 1) + ex.lane_bcast(dacc, 5);
+    const double s2 = ex.lane_bcast(dacc, 2) + ex.lane_bcast(dacc, 6), s3 = ex.lane_bcast(dacc, 3) + ex.lane_bcast(dacc, 7);
+    total = ((s0 + s1) + s2) + s3;
+  }
+  total += tr_dot(x + nb, y + nb, n - nb);
+  return total;
+}
+
 struct OlsLdsFast {
   double *X, *Wv, *Dv, *M, *Lq, *libm, *dump;
   // Lq: L stored column by column, [column k][row i] with row stride SP = NMAX + kOlsPad.  Rows
@@ -265,11 +280,11 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
   L.carve(lds_base, nmax);
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
 
-  typename E::template Reg<double> xr, breg, wreg, sreg, zreg, areg, invd_mine, acc, accprev;
+  typename E::template Reg<double> xr, breg, wreg, sreg, zreg, areg, invd_mine, acc, accprev, dacc;
   typename E::template Reg<int> xnext;
 
   ex.par([&](int l) {
-    xr[l] = 0.0; breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0; accprev[l] = 0.0;
+    xr[l] = 0.0; breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0; accprev[l] = 0.0; dacc[l] = 0.0;
     if (l < no) L.X[l] = 0.0;
     for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
     for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
@@ -293,8 +308,15 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
     });
     ex.sync();
     double pred = 0.0, val = 0.0, ff = 0.0;
+    // slmath::dot with its eight FMA accumulators spread over lanes (lane a runs accumulator a & 7)
+    ex.par([&](int l) {
+      const int a = l & 7;
+      double c = 0.0;
+      for (int i = 0; i + 8 <= no; i += 8) c = fma(L.X[i + a], L.Wv[i + a], c);
+      dacc[l] = c;
+    });
     ex.uni([&]() {
-      pred = dot_canon(L.X, L.Wv, no);
+      pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
       val = (double)self[t];
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
@@ -498,12 +520,12 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
   double *sc = ACC + PW * 64;        // [0] forgetting factor of the step, [1] factorisation ok flag
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
 
-  typename E::template Reg<double> xr, breg, sreg, zreg, invd_mine, accc, lpc;
+  typename E::template Reg<double> xr, breg, sreg, zreg, invd_mine, accc, lpc, dacc;
   typename E::template Reg<OlsArr<PW>> accp;
   typename E::template Reg<int> xnext;
 
   ex.par([&](int l) {
-    xr[l] = 0.0; breg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; invd_mine[l] = 0.0; accc[l] = 0.0; lpc[l] = 0.0;
+    xr[l] = 0.0; breg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; invd_mine[l] = 0.0; accc[l] = 0.0; lpc[l] = 0.0; dacc[l] = 0.0;
     for (int c = 0; c < PW; c++) accp[l].v[c] = 0.0;
     if (l < no) L.X[l] = 0.0;
     for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
@@ -532,8 +554,14 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
     });
     ex.sync();
     double pred = 0.0, val = 0.0, ff = 0.0;
+    ex.leader_par([&](int l) {
+      const int a = l & 7;
+      double c = 0.0;
+      for (int i = 0; i + 8 <= no; i += 8) c = fma(L.X[i + a], L.Wv[i + a], c);
+      dacc[l] = c;
+    });
     ex.leader([&]() {
-      pred = dot_canon(L.X, L.Wv, no);
+      pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
       val = (double)self[t];
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
