@@ -33,6 +33,7 @@
 #include <stdexcept>
 #include "common/utils.h"
 #include "libsac/sparse.h"
+#include "file/sac.h"
 #include "opt/opt.h"
 #include "opt/ssc.h"
 
@@ -566,6 +567,37 @@ API int ref_decode_frame(const uint8_t *rec, int len, int nch, int framesize, in
   return n;
 }
 
+
+
+// ---------------------------------------------------------------- .sac container (genuine reader)
+// Opens a .sac file with the genuine Sac class (file/sac.cpp): ReadSACHeader, ReadMD5, then the frame
+// loop of Codec::DecodeFile (libsac.cpp:856-880) with the genuine FrameCoder.  hdr = {numchannels,
+// samplerate, bitspersample, numsamples, max_framelen, metadatasize}; pcm_out planar [nch][numsamples].
+API int ref_read_sac(const char *path, int *hdr, uint8_t *md5, uint8_t *meta, int metacap, int32_t *pcm_out, long long cap) {
+  Sac sac;
+  if (sac.OpenRead(path) != 0) return -1;
+  if (sac.ReadSACHeader() != 0) { sac.Close(); return -2; }
+  sac.ReadMD5(md5);
+  hdr[0] = sac.getNumChannels(); hdr[1] = sac.getSampleRate(); hdr[2] = sac.getBitsPerSample(); hdr[3] = sac.getNumSamples();
+  hdr[4] = sac.mcfg.max_framelen; hdr[5] = (int)sac.mcfg.metadatasize;
+  if ((int)sac.metadata.size() <= metacap) std::copy(sac.metadata.begin(), sac.metadata.end(), meta);
+  const int nch = hdr[0], total = hdr[3];
+  if ((long long)nch * total > cap) { sac.Close(); return -3; }
+  FrameCoder::tsac_cfg cfg = make_cfg(4, 1, 1);
+  FrameCoder fc(nch, (int)sac.mcfg.max_framesize, cfg);
+  int done = 0, frames = 0;
+  while (done < total) {
+    fc.ReadEncoded(sac);
+    fc.Decode();
+    fc.Unpredict();
+    const int n = fc.GetNumSamples();
+    if (n <= 0 || done + n > total) { sac.Close(); return -4; }
+    for (int ch = 0; ch < nch; ch++) std::copy_n(fc.samples[ch].begin(), n, pcm_out + (size_t)ch * total + done);
+    done += n; frames++;
+  }
+  sac.Close();
+  return frames;
+}
 
 // ---------------------------------------------------------------- adaptive sub-frame split
 // Genuine Codec::Analyse (+ AnalyseSparse / PushState, SparsePCM) on one read of `samples_read`

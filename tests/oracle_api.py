@@ -188,6 +188,17 @@ class Checker:
         self.f("sparse_cost")(_vp(buf), buf.size, _vp(out))
         return float(out[0]), float(out[1])
 
+    # ---- .sac container, genuine reader (ref only)
+    def read_sac(self, path, nch_hint=2, cap_samples=1 << 22):
+        hdr = np.zeros(6, np.int32); md5 = np.zeros(16, np.uint8); meta = np.zeros(1 << 16, np.uint8)
+        pcm = np.zeros(cap_samples, np.int32)
+        fn = self.f("read_sac"); fn.restype = ctypes.c_int
+        nf = fn(ctypes.c_char_p(path.encode()), _vp(hdr), _vp(md5), _vp(meta), meta.size, _vp(pcm), ctypes.c_longlong(pcm.size))
+        assert nf > 0, nf
+        nch, total = int(hdr[0]), int(hdr[3])
+        return dict(numchannels=nch, samplerate=int(hdr[1]), bitspersample=int(hdr[2]), numsamples=total, max_framelen=int(hdr[4]),
+                    metadatasize=int(hdr[5])), md5.tobytes(), meta[: int(hdr[5])].tobytes(), pcm[: nch * total].reshape(nch, total).copy(), nf
+
     # ---- search helpers
     def rng(self, kinds, args=None):
         kinds = np.ascontiguousarray(kinds, np.int32)

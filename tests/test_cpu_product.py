@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from golden_cases import trace_cases
-from oracle_api import _vp, center_frame
+from oracle_api import _vp, center_frame, frame_cfg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -146,3 +146,62 @@ def test_subframe_state_machine_host(orc):
             c = np.mean([orc.sparse_cost(pcm[ch, b * blk: b * blk + ln])[1] for ch in range(pcm.shape[0])])
             states.append(int(c > 1.35))
         assert api.subframes_from_states(states, lens, min_len) == orc.plan_subframes(pcm, blk, min_len), name
+
+
+def test_wav_container_roundtrip():
+    """WAV parse -> metadata pack -> unpack -> rebuilt WAV is byte-identical (incl. odd-sized and
+    trailing chunks); header fields as Wav::ReadHeader reads them."""
+    from sac_amd import container as C
+    from sac_amd.synth import synth_pcm
+    pcm = synth_pcm(1001, 2, 5, 8000)
+    extra = [(0x5453494C, b"INFOISFT\x05\x00\x00\x00abcde"), (0x6B6E756A, b"xyz")]     # LIST (odd inner), 'junk' odd size
+    blob = C.wav_bytes_from_pcm(pcm, 8000, 16, extra_chunks=extra)
+    w = C.parse_wav(blob)
+    assert (w.numchannels, w.samplerate, w.bitspersample, w.numsamples, w.blockalign) == (2, 8000, 16, 1001, 4)
+    assert np.array_equal(C.pcm_from_wav(w), pcm)
+    meta = C.pack_metadata(w.chunks)
+    assert len(meta) == w.metadatasize
+    assert C.unpack_metadata(meta) == w.chunks
+    assert C.rebuild_wav(C.unpack_metadata(meta), w.data) == blob
+    # trailing chunk after the data chunk, 8-bit mono (even byte count: the reference's seek past a
+    # non-final data chunk is not word-aligned, wav.cpp:243-245, so odd sizes derail its own parser)
+    pcm8 = synth_pcm(776, 1, 6, 8000, bits=8)
+    b8 = C.wav_bytes_from_pcm(pcm8, 8000, 8)
+    b8 = b8[:4] + (len(b8) - 8 + 12).to_bytes(4, "little") + b8[8:] + b"cue " + (4).to_bytes(4, "little") + b"\1\2\3\4"
+    w8 = C.parse_wav(b8)
+    assert w8.numsamples == 776 and np.array_equal(C.pcm_from_wav(w8), pcm8)
+    assert C.rebuild_wav(C.unpack_metadata(C.pack_metadata(w8.chunks)), w8.data) == b8
+    # odd number of 8-bit samples in a final data chunk: pad byte restored
+    b9 = C.wav_bytes_from_pcm(synth_pcm(777, 1, 7, 8000, bits=8), 8000, 8)
+    w9 = C.parse_wav(b9)
+    assert w9.numsamples == 777 and C.rebuild_wav(C.unpack_metadata(C.pack_metadata(w9.chunks)), w9.data) == b9
+
+
+@pytest.mark.ref
+def test_sac_file_is_read_by_the_genuine_reference(orc, ref, tmp_path):
+    """A .sac file written by sac_amd.container (records from the oracle) is opened by the genuine
+    Sac::ReadSACHeader / ReadMD5 and decoded frame by frame by the genuine FrameCoder: header fields,
+    MD5, metadata bytes and PCM all agree."""
+    import hashlib
+    from sac_amd import container as C
+    from sac_amd.synth import synth_pcm
+    rate, maxlen = 8000, 1
+    pcm = synth_pcm(2 * rate + 345, 2, 9, rate)
+    blob = C.wav_bytes_from_pcm(pcm, rate, 16, extra_chunks=[(0x5453494C, b"INFOICMT\x04\x00\x00\x00test")])
+    w = C.parse_wav(blob)
+    recs, pos = [], 0
+    while pos < w.numsamples:                                  # frame loop of Codec::EncodeFile without adapt_block
+        n = min(maxlen * rate, w.numsamples - pos)
+        recs.append(orc.encode_frame(pcm[:, pos: pos + n], frame_cfg("normal"), maxlen * rate)["record"])
+        pos += n
+    path = str(tmp_path / "t.sac")
+    C.write_sac(path, w, maxlen, recs)
+    hdr, md5, meta, dec, nframes = ref.read_sac(path)
+    assert hdr == dict(numchannels=2, samplerate=rate, bitspersample=16, numsamples=w.numsamples, max_framelen=maxlen,
+                       metadatasize=w.metadatasize)
+    assert md5 == hashlib.md5(w.data).digest()
+    assert meta == C.pack_metadata(w.chunks)
+    assert nframes == len(recs) == 3
+    assert np.array_equal(dec, pcm)
+    h2, m2, chunks2, recs2 = C.read_sac(path)
+    assert recs2 == recs and chunks2 == w.chunks and m2 == md5

@@ -255,3 +255,49 @@ def test_edge_frames_ragged_batch_vs_oracle(api, orc):
         assert rec == want, f.shape
         dec, _ = orc.decode_frame(rec, 2, FRAMESIZE)
         assert np.array_equal(dec, f)
+
+
+def test_baseline_configs_3_and_4_small(api, orc):
+    """BASELINE.json configs[3] (--best: bitplane cost, fraction 0.5, sigma 0.25) and configs[4]
+    (--veryhigh on a mixed 8-bit mono + 16-bit stereo corpus) at sizes the oracle finishes in
+    seconds: frame records byte-identical to the oracle's, same DDS-chosen profile."""
+    n = 3000
+    cases = [("best", synth_pcm(n, 2, 301, RATE), dict(num_threads=4, maxnfunc=12)),
+             ("veryhigh", synth_pcm(n, 1, 302, RATE, bits=8), dict(num_threads=4, maxnfunc=16)),
+             ("veryhigh", synth_pcm(n, 2, 303, RATE), dict(num_threads=4, maxnfunc=16)),
+             ("veryhigh", synth_pcm(n, 2, 304, RATE, sparse_bits=10), dict(num_threads=4, maxnfunc=16))]
+    for mode, raw, kw in cases:
+        fs = 4 * RATE                                   # max frame size: search window = fraction * fs
+        want = orc.encode_frame(raw, frame_cfg(mode, **kw), fs)
+        ctx = api.Context(raw.shape[0], fs, 1)
+        ctx.upload_i32([raw], fs)
+        recs, prof = ctx.encode_frames(api.make_cfg(mode, **kw))
+        ctx.close()
+        assert np.array_equal(prof[0], want["profile"]), mode
+        assert recs[0] == want["record"], mode
+
+
+def test_wav_to_sac_file_end_to_end(api, orc, tmp_path):
+    """WAV bytes -> GPU encode (sub-frame split, batch) -> .sac file -> frames decode to the WAV's
+    samples; with the genuine reference objects available the file is opened by the genuine
+    Sac reader as well."""
+    import hashlib
+    from sac_amd import container as C
+    rate, maxlen = RATE, 4
+    pcm = synth_pcm(9 * rate + 77, 2, 404, rate) >> 3
+    pcm[:, 3 * rate: 6 * rate] = (pcm[:, 3 * rate: 6 * rate] // 16) * 16
+    blob = C.wav_bytes_from_pcm(pcm, rate, 16, extra_chunks=[(0x5453494C, b"INFOICMT\x04\x00\x00\x00test")])
+    ctx = api.Context(2, maxlen * rate, 8)
+    (info, recs), = C.encode_wav_files(ctx, [blob], api.make_cfg("normal"), max_framelen=maxlen)
+    ctx.close()
+    path = str(tmp_path / "e2e.sac")
+    C.write_sac(path, info, maxlen, recs)
+    hdr, md5, chunks, recs2 = C.read_sac(path)
+    assert recs2 == recs and md5 == hashlib.md5(info.data).digest()
+    dec = np.concatenate([orc.decode_frame(r, 2, maxlen * rate)[0] for r in recs2], axis=1)
+    assert np.array_equal(dec, pcm)
+    assert C.rebuild_wav(chunks, dec.T.astype("<i2").tobytes()) == blob
+    if ref_available():
+        from oracle_api import Checker
+        h, m, meta, d, nf = Checker("ref").read_sac(path)
+        assert np.array_equal(d, pcm) and nf == len(recs) and m == md5 and meta == C.pack_metadata(info.chunks)
