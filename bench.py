@@ -235,7 +235,7 @@ def main():
         ols_nmax = (16, 24, 32, 40, 48, 56, 64, 96)
         def kname(kind, cls):
             if kind == "ols":
-                return f"k_ols<{64 if cls < 3 else (256 if cls < 7 else 128)},{ols_nmax[cls]}>"
+                return f"k_ols<{64 if cls < 3 else 256},{ols_nmax[cls]}>"
             return f"k_lms<{cls}>"
         cands = {}
         for (kind, cls), (ms, launches, isteps) in ct.items():

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
   ExecDev<NL> ex;
   if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
+  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
   else if constexpr (NL == 256 || NL == 512) ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
   else ols_stage(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
 }
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
 template <int NL, int NMAX>
 static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
   static bool once = false;
-  const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : ((NL == 256 || NL == 512) ? ols_panel_lds_bytes(NMAX, NL / 64) : OlsLds::bytes(NMAX));
+  const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : ((NL == 256 && NMAX > 64) ? ols_panel2_lds_bytes(NMAX) : ((NL == 256 || NL == 512) ? ols_panel_lds_bytes(NMAX, NL / 64) : OlsLds::bytes(NMAX)));
   if (!once) { (void)hipFuncSetAttribute((const void *)k_ols<NL, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); once = true; }
   hipLaunchKernelGGL((k_ols<NL, NMAX>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_p);
 }
@@ -76,7 +77,7 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 4: launch_ols_c<kOlsPanelThreads, 48>(s, d_items, d_idx, count, v, d_p); break;
     case 5: launch_ols_c<kOlsPanelThreads, 56>(s, d_items, d_idx, count, v, d_p); break;
     case 6: launch_ols_c<kOlsPanelThreads, 64>(s, d_items, d_idx, count, v, d_p); break;
-    default: launch_ols_c<128, 96>(s, d_items, d_idx, count, v, d_p); break;
+    default: launch_ols_c<256, 96>(s, d_items, d_idx, count, v, d_p); break;   // 65..96: panel factorisation, two rows per lane
   }
 }
 

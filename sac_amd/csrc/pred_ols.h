@@ -736,6 +736,273 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
 #undef SA_TICK
 }
 
+// ---------------------------------------------------------------------------------------------
+// Regressors of 65..128 taps: the panel factorisation of ols_stage_panel with TWO matrix rows per
+// lane (rows r and r + 64 of lane r).  Same element-by-element arithmetic; every per-row register
+// becomes a pair, broadcasts pick the half that owns the row.  One workgroup (four waves) per CU.
+template <class E, int NMAX>
+SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const int *other, int n,
+                            double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
+  constexpr int NL = E::nl;
+  constexpr int PW = NL / 64;
+  static_assert(PW == 4 && NMAX > 64 && NMAX <= 128, "four waves, two rows per lane");
+  constexpr int S = NMAX + kOlsPad;
+  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
+#define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
+  const int no = p.n_ols;
+  const int ntri = tri_count(no);
+  OlsLdsFast L;
+  L.carve(lds_base, NMAX);
+  double *ACC = L.Lq + NMAX * S;     // [PW][2][64] phase-1 results
+  double *sc = ACC + PW * 2 * 64;    // [0] forgetting factor of the step, [1] factorisation ok flag
+  const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
+
+  typedef OlsArr<2> D2;
+  typename E::template Reg<D2> xr, breg, sreg, zreg, invd_mine, accc, lpc;
+  typename E::template Reg<OlsArr<2 * PW>> accp;
+  typename E::template Reg<double> dacc, tmpb;
+  struct I2 { int v[2]; };
+  typename E::template Reg<I2> xnext;
+
+  ex.par([&](int l) {
+    for (int h = 0; h < 2; h++) {
+      xr[l].v[h] = 0.0; breg[l].v[h] = 0.0; sreg[l].v[h] = 0.0; zreg[l].v[h] = 0.0; invd_mine[l].v[h] = 0.0; accc[l].v[h] = 0.0; lpc[l].v[h] = 0.0;
+      const int row = l + 64 * h;
+      xnext[l].v[h] = (l < 64 && row < no && n > 0) ? ols_x(p, self, other, n, 0, row) : 0;
+    }
+    for (int c = 0; c < 2 * PW; c++) accp[l].v[c] = 0.0;
+    dacc[l] = 0.0; tmpb[l] = 0.0;
+    for (int e = l; e < NMAX; e += NL) L.X[e] = 0.0;
+    for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
+    for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
+    for (int e = l; e < NMAX * S; e += NL) L.Lq[e] = 0.0;
+    for (int e = l; e < PW * 2 * 64; e += NL) ACC[e] = 0.0;
+    if (l < 4) sc[l] = 0.0;
+    sa_stage_tables(L.libm, l, NL);
+  });
+  ex.sync();
+
+  double esum = 0.0;
+  int km = 0;
+  const double lambda = p.lambda, nu = p.nu_eff;
+  const double one_m_lambda = 1.0 - lambda;
+
+  if (prof) tc = E::clock();
+  for (int t = 0; t < n; t++) {
+    ex.par([&](int l) {
+      if (l < 64) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int row = l + 64 * h;
+          xr[l].v[h] = (double)xnext[l].v[h];
+          if (row < no) L.X[row] = xr[l].v[h];
+          if (row < no && t + 1 < n) xnext[l].v[h] = ols_x(p, self, other, n, t + 1, row);
+        }
+      }
+    });
+    ex.sync();
+    double pred = 0.0, val = 0.0, ff = 0.0;
+    ex.leader_par([&](int l) {
+      const int a = l & 7;
+      double c = 0.0;
+      for (int i = 0; i + 8 <= no; i += 8) c = fma(L.X[i + a], L.Wv[i + a], c);
+      dacc[l] = c;
+    });
+    ex.leader([&]() {
+      pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
+      val = (double)self[t];
+      const double e = val - pred;
+      esum = fma(p.beta_sum, esum, fabs(e));
+      const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
+      ff = one_m_lambda * c;
+    });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; } });
+    ex.sync();
+    SA_TICK(0);
+    // covariance / rhs update: lane = rows r, r+64; wave w takes the column groups 8w, 8w+32, ..
+    ex.par([&](int l) {
+      const int w = l >> 6, r = l & 63;
+      const double ffl = sc[0];
+      double *dump = L.dump;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int row = r + 64 * h;
+        if (row < no) {
+          const double xi = L.X[row];
+          for (int j = 8 * w; j < no; j += 8 * PW) {
+            double m[8], xj[8];
+            int e[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int jj = j + u < no ? j + u : no - 1;
+              e[u] = tri_off(no, jj) + (row - jj); xj[u] = L.X[jj]; m[u] = L.M[e[u] < 0 ? 0 : e[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const double v = fma(lambda, m[u], ffl * (xi * xj[u]));
+              double *dst = (row >= j + u && j + u < no) ? &L.M[e[u]] : dump;
+              *dst = v;
+            }
+          }
+          if (w == 0) breg[l].v[h] = fma(lambda, breg[l].v[h], ff * (xi * val));
+        }
+      }
+    });
+    SA_TICK(1);
+    km++;
+    if (km >= p.k) {
+      km = 0;
+      ex.par([&](int l) {
+        for (int e = l; e < NMAX + kOlsPad; e += NL) L.Dv[e] = 0.0;
+        if (l == 0) sc[1] = 1.0;
+      });
+      ex.sync();                                   // M complete, D cleared
+      bool ok = true;
+      for (int p4 = 0; p4 < no; p4 += PW) {
+        const int nchunk = (p4 + 7) >> 3;           // chunks cover k < 8*nchunk <= NMAX; k >= p4 is masked by D == 0
+        ex.par([&](int l) {
+          const int w = l >> 6, r = l & 63;
+          const int j = p4 + w;
+          if (j < no) {
+            double s_[2];
+            const double *pa[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int row = r + 64 * h;
+              const int rm = row < no ? row : no - 1;
+              s_[h] = L.M[tri_off(no, j) + (rm - j) < 0 ? 0 : tri_off(no, j) + (rm - j)];
+              if (row == j) s_[h] = s_[h] + nu;
+              pa[h] = L.Lq + (row < S ? row : S - 1);   // own row: element k at pa[k*S]
+            }
+            const double *pb = L.Lq + j;              // row j
+            struct Fc { double a0[8], a1[8], b[8], d[8]; };
+            auto ld = [&](Fc &c, int m) {
+              const int k = 8 * m;
+#pragma unroll
+              for (int u = 0; u < 8; u++) { c.a0[u] = pa[0][(k + u) * S]; c.a1[u] = pa[1][(k + u) * S]; c.b[u] = pb[(k + u) * S]; c.d[u] = L.Dv[k + u]; }
+            };
+            auto ac = [&](const Fc &c) {
+              double t0[8], t1[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) { t0[u] = c.a0[u] * c.b[u]; t1[u] = c.a1[u] * c.b[u]; }
+#pragma unroll
+              for (int u = 0; u < 8; u++) { t0[u] = t0[u] * c.d[u]; t1[u] = t1[u] * c.d[u]; }
+#pragma unroll
+              for (int u = 0; u < 8; u++) { s_[0] = s_[0] - t0[u]; s_[1] = s_[1] - t1[u]; }
+            };
+            if (nchunk > 0) {
+              Fc A, B;
+              ld(A, 0);
+              int m = 0;
+              while (true) {
+                if (m + 1 < nchunk) ld(B, m + 1);
+                ac(A);
+                if (++m >= nchunk) break;
+                if (m + 1 < nchunk) ld(A, m + 1);
+                ac(B);
+                if (++m >= nchunk) break;
+              }
+            }
+            ACC[(w * 2 + 0) * 64 + r] = s_[0];
+            ACC[(w * 2 + 1) * 64 + r] = s_[1];
+          }
+        });
+        ex.sync();
+        if (E::is_leader()) {
+          // phase 2 (wave 0): right-looking inside the panel
+          ex.leader_par([&](int l) {
+#pragma unroll
+            for (int c = 0; c < 2 * PW; c++) accp[l].v[c] = ACC[c * 64 + l];
+          });
+#pragma unroll
+          for (int c = 0; c < PW; c++) {
+            const int j = p4 + c;
+            if (j >= no || !ok) break;
+            const int hj = j >> 6, lj = j & 63;
+            ex.leader_par([&](int l) { accc[l].v[0] = accp[l].v[2 * c]; accc[l].v[1] = accp[l].v[2 * c + 1]; tmpb[l] = hj ? accc[l].v[1] : accc[l].v[0]; });
+            const double dj = ex.lane_bcast(tmpb, lj);
+            if (dj < 1e-12) { ok = false; break; }
+            const double invd = 1.0 / dj;
+            ex.leader_par([&](int l) {
+#pragma unroll
+              for (int h = 0; h < 2; h++) {
+                const int row = l + 64 * h;
+                const double v = accc[l].v[h] * invd;
+                lpc[l].v[h] = v;
+                if (row > j && row < no) L.Lq[j * S + row] = v;
+                if (row == j) invd_mine[l].v[h] = invd;
+              }
+              if (l == 0) L.Dv[j] = dj;
+            });
+#pragma unroll
+            for (int c2 = c + 1; c2 < PW; c2++) {
+              const int j2 = p4 + c2;
+              const int jb = j2 < NMAX ? j2 : NMAX - 1;
+              const int hb = jb >> 6;
+              ex.leader_par([&](int l) { tmpb[l] = hb ? lpc[l].v[1] : lpc[l].v[0]; });
+              const double bq = ex.lane_bcast(tmpb, jb & 63);
+              const bool fz = (c2 == c + 1) && (j2 & 1);          // k = j2-1 with j2 odd: the fused last term
+              ex.leader_par([&](int l) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                  const double tt = lpc[l].v[h] * bq;
+                  accp[l].v[2 * c2 + h] = fz ? fma(-tt, dj, accp[l].v[2 * c2 + h]) : accp[l].v[2 * c2 + h] - tt * dj;
+                }
+              });
+            }
+          }
+          ex.leader_par([&](int l) { if (l == 0 && !ok) sc[1] = 0.0; });
+        }
+        ex.sync();
+        ok = sc[1] != 0.0;
+        if (!ok) break;
+      }
+      SA_TICK(2);
+      if (ok && E::is_leader()) {
+        // forward solve: column sweep with register broadcasts (wave 0)
+        ex.leader_par([&](int l) { sreg[l].v[0] = breg[l].v[0]; sreg[l].v[1] = breg[l].v[1]; });
+#pragma unroll 1
+        for (int kk = 0; kk + 1 < no; kk++) {
+          const int hk = kk >> 6;
+          ex.leader_par([&](int l) { tmpb[l] = hk ? sreg[l].v[1] : sreg[l].v[0]; });
+          const double yk = ex.lane_bcast(tmpb, kk & 63);
+          ex.leader_par([&](int l) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int row = l + 64 * h;
+              const double lv = L.Lq[kk * S + (row < S ? row : S - 1)];
+              const double v = fold_fused(kk, row) ? fma(-lv, yk, sreg[l].v[h]) : sreg[l].v[h] - lv * yk;
+              if (row > kk && row < no) sreg[l].v[h] = v;
+            }
+          });
+        }
+        ex.leader_par([&](int l) { zreg[l].v[0] = sreg[l].v[0] * invd_mine[l].v[0]; zreg[l].v[1] = sreg[l].v[1] * invd_mine[l].v[1]; });
+        SA_TICK(3);
+        ex.leader_par([&](int l) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) { const int row = l + 64 * h; if (row < no) L.Dv[row] = zreg[l].v[h]; }     // z into LDS (D is no longer needed)
+        });
+        ex.wsync();
+        ex.lane0([&]() {
+          double wr[NMAX];
+          const double *lb = L.Lq - (NMAX - no) * (S + 1);
+          const double *zb = L.Dv - (NMAX - no);
+          double *wb = L.Wv - (NMAX - no);
+          OlsBwdRows<NMAX, S, 0>::run(no, L.X, lb, zb, wb, wr);
+        });
+        ex.wsync();
+        SA_TICK(4);
+      }
+    }
+    ex.sync();
+    SA_TICK(5);
+  }
+  if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[i] = tp[i]; });
+#undef SA_TICK
+}
+
+SA_HD size_t ols_panel2_lds_bytes(int nmax) { return OlsLdsFast::bytes(nmax) + (size_t)(4 * 2 * 64 + 4) * sizeof(double); }
+
 SA_HD size_t ols_panel_lds_bytes(int nmax, int waves) { return OlsLdsFast::bytes(nmax) + (size_t)(waves * 64 + 4) * sizeof(double); }
 
 }  // namespace sacamd

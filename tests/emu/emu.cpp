@@ -48,7 +48,7 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
       else if (p.n_ols <= 48) EMU_OLSP(48)
       else if (p.n_ols <= 56) EMU_OLSP(56)
       else if (p.n_ols <= 64) EMU_OLSP(64)
-      else { std::vector<char> lds(OlsLds::bytes(128)); ExecEmu<128> ex; ols_stage(ex, p, self, other, n, pl, lds.data(), 128); }
+      else { std::vector<char> lds(ols_panel2_lds_bytes(96)); ExecEmu<256> ex; ols_stage_panel2<ExecEmu<256>, 96>(ex, p, self, other, n, pl, lds.data()); }   // 65..96 taps: two rows per lane
     }
     std::vector<double> tab; double sp[4];
     for (int s = 0; s < 4; s++) {
