@@ -53,14 +53,13 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   ExecDev<NL> ex;
   if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
   else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
-  else if constexpr (NL == 256 || NL == 512) ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
-  else ols_stage(ex, p, self, other, it.n, pbuf + it.off_p, smem, NMAX);
+  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
 }
 
 template <int NL, int NMAX>
 static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
   static bool once = false;
-  const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : ((NL == 256 && NMAX > 64) ? ols_panel2_lds_bytes(NMAX) : ((NL == 256 || NL == 512) ? ols_panel_lds_bytes(NMAX, NL / 64) : OlsLds::bytes(NMAX)));
+  const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : ((NL == 256 && NMAX > 64) ? ols_panel2_lds_bytes(NMAX) : ols_panel_lds_bytes(NMAX, NL / 64));
   if (!once) { (void)hipFuncSetAttribute((const void *)k_ols<NL, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); once = true; }
   hipLaunchKernelGGL((k_ols<NL, NMAX>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_p);
 }

@@ -9,11 +9,12 @@
 // (frame x candidate x channel) it is a self-contained recurrence that can run ahead of the
 // cascade and bias stages and hand p_lpc[t] over through HBM.
 //
-// One workgroup (one or two waves) per work-item.  The covariance estimate and the LDL^T
-// workspace live in LDS as packed column-major lower triangles; the factorisation is done
-// right-looking (all trailing elements of a column step in parallel) but applies to every
-// element exactly the reference's left-looking subtraction chain -- same terms, same order, same
-// fused/unfused pattern (canon.h) -- so p_lpc is bit-identical to the reference build.
+// One workgroup per work-item: one wave up to 32 taps (ols_stage_fast), four waves for 33..64
+// (ols_stage_panel) and 65..96 (ols_stage_panel2, two matrix rows per lane).  Lane = matrix row;
+// the covariance estimate (packed lower triangle) and L (column-major, zero padded) live in LDS.
+// Whatever the schedule, every element sees exactly the reference's left-looking subtraction
+// chain -- same terms, same order, same fused/unfused pattern (canon.h) -- so p_lpc is
+// bit-identical to the reference build.
 #pragma once
 #include "canon.h"
 #include "libm_port.h"
@@ -23,21 +24,6 @@ namespace sacamd {
 
 SA_HD int tri_off(int n, int j) { return j * n - (j * (j - 1)) / 2; }   // start of column j
 SA_HD int tri_count(int n) { return n * (n + 1) / 2; }
-
-// LDS carve-up for one OLS work-item (doubles first, then u16 table)
-struct OlsLds {
-  double *X, *Wv, *Y, *Z, *D, *invD, *M, *Wk;
-  unsigned short *tab;
-  SA_HD static size_t bytes(int nmax) {
-    return (size_t)(6 * nmax + 2 * tri_count(nmax)) * sizeof(double) + (size_t)tri_count(nmax) * 2 + 16;
-  }
-  SA_HD void carve(char *base, int nmax) {
-    double *d = reinterpret_cast<double *>(base);
-    X = d; d += nmax; Wv = d; d += nmax; Y = d; d += nmax; Z = d; d += nmax; D = d; d += nmax; invD = d; d += nmax;
-    M = d; d += tri_count(nmax); Wk = d; d += tri_count(nmax);
-    tab = reinterpret_cast<unsigned short *>(d);
-  }
-};
 
 // regressor element j at step t (zero outside the window), pred.cpp:17-31
 SA_HD int ols_x(const ChanParam &p, const int *self, const int *other, int n, int t, int j) {
@@ -51,141 +37,12 @@ SA_HD int ols_x(const ChanParam &p, const int *self, const int *other, int n, in
   return (i >= 0 && i < n) ? other[i] : 0;
 }
 
-// E::nl must be >= n_ols.  self/other point at the start of the window.
-template <class E>
-SA_HD void ols_stage(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                     double *p_out, char *lds_base, int nmax) {
-  const int no = p.n_ols;
-  const int ntri = tri_count(no);
-  OlsLds L;
-  L.carve(lds_base, nmax);
-
-  typename E::template Reg<double> breg;   // b[j], lane j
-  typename E::template Reg<double> sreg;   // forward-solve accumulator, lane r
-  typename E::template Reg<int> xnext;     // prefetched regressor element for the next step
-
-  // ---- init
-  ex.par([&](int l) {
-    breg[l] = 0.0; sreg[l] = 0.0;
-    if (l < no) { L.X[l] = 0.0; L.Wv[l] = 0.0; L.Y[l] = 0.0; L.Z[l] = 0.0; L.D[l] = 0.0; L.invD[l] = 0.0; }
-    for (int e = l; e < ntri; e += E::nl) { L.M[e] = 0.0; L.Wk[e] = 0.0; }
-    // (row,col) of packed element e: column j holds rows j..no-1
-    for (int j = l; j < no; j += E::nl) {
-      const int o = tri_off(no, j);
-      for (int i = j; i < no; i++) L.tab[o + (i - j)] = (unsigned short)((i << 8) | j);
-    }
-    xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
-  });
-  ex.sync();
-
-  double esum = 0.0;
-  int km = 0;
-  const double lambda = p.lambda, nu = p.nu_eff;
-  const double one_m_lambda = 1.0 - lambda;
-
-  for (int t = 0; t < n; t++) {
-    // (1) regressor
-    ex.par([&](int l) {
-      if (l < no) L.X[l] = (double)xnext[l];
-      if (l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
-    });
-    ex.sync();
-    // (2) predict -- canonical order, uniform across lanes
-    double pred = 0.0, val = 0.0, ff = 0.0;
-    ex.uni([&]() {
-      pred = dot_canon(L.X, L.Wv, no);
-      val = (double)self[t];
-      const double e = val - pred;
-      esum = fma(p.beta_sum, esum, fabs(e));
-      const double c = sa_pow(esum + p.beta_add, -p.beta_pow);
-      ff = one_m_lambda * c;
-    });
-    ex.par([&](int l) { if (l == 0) p_out[t] = pred; });
-    // (3) covariance / rhs update (ols.cpp:38-45)
-    ex.par([&](int l) {
-      for (int e = l; e < ntri; e += E::nl) {
-        const int ij = L.tab[e];
-        const double xr = L.X[ij >> 8], xc = L.X[ij & 255];
-        L.M[e] = fma(lambda, L.M[e], ff * (xr * xc));
-      }
-      if (l < no) breg[l] = fma(lambda, breg[l], ff * (L.X[l] * val));
-    });
-    km++;
-    if (km >= p.k) {
-      km = 0;
-      // ---- factor (right-looking, reference chain order per element)
-      ex.par([&](int l) {
-        for (int e = l; e < ntri; e += E::nl) {
-          const int ij = L.tab[e];
-          const double m = L.M[e];
-          L.Wk[e] = ((ij >> 8) == (ij & 255)) ? m + nu : m;
-        }
-      });
-      ex.sync();
-      bool ok = true;
-      for (int kk = 0; kk < no; kk++) {
-        const int ok0 = tri_off(no, kk);
-        double dk = 0.0, invd = 0.0;
-        ex.uni([&]() { dk = L.Wk[ok0]; });
-        if (dk < 1e-12) { ok = false; break; }
-        ex.uni([&]() { invd = 1.0 / dk; });
-        ex.par([&](int l) {
-          if (l == 0) { L.D[kk] = dk; L.invD[kk] = invd; }
-          for (int i = kk + 1 + l; i < no; i += E::nl) L.Wk[ok0 + (i - kk)] = L.Wk[ok0 + (i - kk)] * invd;
-        });
-        ex.sync();
-        const int e0 = tri_off(no, kk + 1);
-        ex.par([&](int l) {
-          for (int e = e0 + l; e < ntri; e += E::nl) {
-            const int ij = L.tab[e];
-            const int i = ij >> 8, j = ij & 255;
-            const double tt = L.Wk[ok0 + (i - kk)] * L.Wk[ok0 + (j - kk)];
-            const double w = L.Wk[e];
-            L.Wk[e] = fold_fused(kk, j) ? fma(-tt, dk, w) : w - tt * dk;
-          }
-        });
-        ex.sync();
-      }
-      if (ok) {
-        // ---- forward solve L y = b (column sweep == the reference's per-row chains)
-        ex.par([&](int l) { sreg[l] = breg[l]; });
-        for (int kk = 0; kk < no; kk++) {
-          ex.par([&](int l) { if (l == kk) L.Y[kk] = sreg[l]; });
-          ex.sync();
-          const int ok0 = tri_off(no, kk);
-          ex.par([&](int l) {
-            if (l > kk && l < no) {
-              const double lv = L.Wk[ok0 + (l - kk)], yk = L.Y[kk];
-              sreg[l] = fold_fused(kk, l) ? fma(-lv, yk, sreg[l]) : sreg[l] - lv * yk;
-            }
-          });
-        }
-        ex.par([&](int l) { if (l < no) L.Z[l] = L.Y[l] * L.invD[l]; });
-        ex.sync();
-        // ---- backward solve L^T w = z: strictly serial chains (math.h:67-72), all fused
-        ex.uni([&]() {
-          for (int i = no - 1; i >= 0; --i) {
-            double s = L.Z[i];
-            const int oi = tri_off(no, i);
-            for (int kk = i + 1; kk < no; ++kk) s = fma(-L.Wk[oi + (kk - i)], L.Wv[kk], s);
-            L.Wv[i] = s;
-          }
-        });
-      }
-    }
-    ex.sync();   // X / M are rewritten by the next step (matters when the workgroup has 2 waves)
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Fast path for one-wave workgroups (E::nl == 64, n_ols <= 64).  Same arithmetic as ols_stage
-// (bit-identical results); what changes is where values live and how they travel:
-//  * x, b, w, the forward/backward-solve vectors: one element per lane in registers, moved with
-//    v_readlane broadcasts instead of LDS round trips + barriers;
-//  * LDL^T column step: the pivot is always produced by lane 0's first trailing element, so it is
-//    handed on in a register; scaling of the column and the trailing update share one phase
-//    (the scaled column goes to a second triangle, Lk), leaving one barrier per column;
-//  * the element loops issue their LDS loads four elements at a time.
+// One-wave workgroups (E::nl == 64, n_ols <= 64; launched for <= 32 taps):
+//  * x, b and the forward-solve vector: one element per lane in registers, moved with v_readlane
+//    broadcasts instead of LDS round trips + barriers;
+//  * LDL^T left-looking by columns, chains in whole 8-term chunks (see ols_stage_fast);
+//  * back-substitution fully unrolled, anchored at the last row (OlsBwdRows).
 struct DArr4 { double v[4]; };
 constexpr int kOlsPad = 8;
 
