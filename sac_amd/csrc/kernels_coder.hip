@@ -50,8 +50,9 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   if (count <= 0) return;
   static bool once = false;
   if (!once) { (void)hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::bytes(kCoderStreamsPerWg)); once = true; }
-  // up to 512 streams fit as one-stream workgroups, two per CU; beyond that pack four per workgroup
-  const int spw = count <= 512 ? 1 : kCoderStreamsPerWg;
+  // the fewest streams per CU that still keep every stream resident at once (256 CUs): one-stream
+  // workgroups (two per CU) up to 512 streams, three per workgroup up to 768, four beyond
+  const int spw = count <= 512 ? 1 : (count <= 768 ? 3 : kCoderStreamsPerWg);
   const int wgs = (count + spw - 1) / spw;
   hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_s2u_map, d_used, d_laplace,
                      d_fwd, d_inv, d_state, state_stride, d_out, d_len);
