@@ -1,0 +1,145 @@
+// sac_amd/csrc/sacenc.cpp -- command-line encoder on top of the C ABI: WAV -> .sac on an MI355X.
+//
+//   sacenc [--normal|--high|--veryhigh|--extrahigh|--best|--insane] [--opt-cfg=dds,N] [--framelen=S]
+//          [--adapt-block=no] [--max-frames=N] in.wav [more.wav ...] out.sac|outdir
+//
+// The encode side of the reference's command line (/root/reference/src/cmdline.cpp:127-235) and of
+// Codec::EncodeFile (libsac/libsac.cpp:782-855): reads of framelen seconds, adaptive sub-frame split
+// (sacamd_plan_subframes), every frame of every input file staged as ONE batch per max-frames
+// (frames are independent: --opt-reset semantics), records written behind the SAC2 header + MD5.
+// With several inputs the last argument is a directory.  Host code only; no CPU compute path.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/sac_amd.h"
+#include "sacfile.h"
+
+using namespace sacamd;
+
+static std::vector<uint8_t> slurp(const std::string &p) {
+  std::ifstream f(p, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open " + p);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+struct FrameRef { int file, start, length; };
+
+int main(int argc, char **argv) {
+  try {
+    sacamd_cfg cfg; sacamd_default_cfg(&cfg);
+    cfg.reset = 1;
+    int framelen = 20, adapt_block = 1, max_frames = 256;
+    bool header_only = false;      // --header-only: write header + MD5 of each input and stop (no device needed; tests)
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; i++) {
+      std::string a = argv[i];
+      auto preset = [&](int opt, double frac, int e, double sig, int cost) { cfg.optimize = opt; cfg.fraction = frac; cfg.maxnfunc = e; cfg.sigma = sig; cfg.optimize_cost = cost; };
+      if (a == "--normal") preset(0, 0.0, 0, 0.2, SACAMD_COST_ENTROPY);                 // cmdline.cpp:127-156
+      else if (a == "--high") preset(1, 0.1, 100, 0.20, SACAMD_COST_ENTROPY);
+      else if (a == "--veryhigh") preset(1, 0.2, 300, 0.25, SACAMD_COST_ENTROPY);
+      else if (a == "--extrahigh") preset(1, 0.2, 600, 0.25, SACAMD_COST_ENTROPY);
+      else if (a == "--best") preset(1, 0.5, 1000, 0.25, SACAMD_COST_BITPLANE);
+      else if (a == "--insane") preset(1, 0.5, 1500, 0.25, SACAMD_COST_BITPLANE);
+      else if (a.rfind("--opt-cfg=dds,", 0) == 0) cfg.num_threads = std::atoi(a.c_str() + 14);
+      else if (a.rfind("--framelen=", 0) == 0) framelen = std::atoi(a.c_str() + 11);
+      else if (a == "--adapt-block=no" || a == "--adapt-block=0") adapt_block = 0;
+      else if (a.rfind("--max-frames=", 0) == 0) max_frames = std::atoi(a.c_str() + 13);
+      else if (a == "--header-only") header_only = true;
+      else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
+      else pos.push_back(a);
+    }
+    if (pos.size() < 2 || framelen < 1 || framelen > 255 || max_frames < 1) { std::cerr << "usage: sacenc [options] in.wav [more.wav ...] out.sac|outdir\n"; return 2; }
+    const std::string outarg = pos.back(); pos.pop_back();
+    const bool multi = pos.size() > 1;
+
+    std::vector<WavInfo> wavs;
+    std::vector<std::vector<int32_t>> pcm;
+    for (auto &p : pos) { wavs.push_back(parse_wav(slurp(p))); pcm.push_back(pcm_from_wav(wavs.back())); }
+    const int nch = wavs[0].numchannels, rate = wavs[0].samplerate;
+    for (auto &w : wavs) if (w.numchannels != nch || w.samplerate != rate) throw std::runtime_error("all inputs of one run must share channel count and sample rate");
+    const int maxfs = framelen * rate;
+    if (header_only) {
+      if (multi) throw std::runtime_error("--header-only takes one input");
+      const std::vector<uint8_t> hdr = sac_header_and_md5(wavs[0], framelen);
+      std::ofstream o(outarg, std::ios::binary);
+      o.write((const char *)hdr.data(), (std::streamsize)hdr.size());
+      return 0;
+    }
+
+    sacamd_ctx *ctx = nullptr;
+    if (sacamd_ctx_create(0, nch, maxfs, max_frames, &ctx) != 0) throw std::runtime_error("no usable gfx950 device (sacamd_ctx_create failed)");
+    auto chk = [&](int rc) { if (rc != 0) throw std::runtime_error(std::string("sac_amd: ") + sacamd_last_error(ctx)); };
+
+    // frame list: reads of maxfs samples, each cut into sub-frames (libsac.cpp:805-820)
+    std::vector<FrameRef> frames;
+    for (size_t f = 0; f < wavs.size(); f++) {
+      const int total = wavs[f].numsamples;
+      for (int p0 = 0; p0 < total; p0 += maxfs) {
+        const int n = std::min(maxfs, total - p0);
+        if (adapt_block) {
+          sacamd_subframe sf[64]; int cnt = 0;
+          chk(sacamd_plan_subframes(ctx, pcm[f].data() + p0, total, nch, n, 3 * rate, 3 * rate, sf, 64, &cnt));
+          for (int i = 0; i < cnt; i++) frames.push_back({(int)f, p0 + sf[i].start, sf[i].length});
+        } else frames.push_back({(int)f, p0, n});
+      }
+    }
+
+    // encode in batches of max_frames
+    std::vector<std::vector<uint8_t>> payload(wavs.size());
+    std::vector<int> nfr(wavs.size(), 0);
+    for (size_t b0 = 0; b0 < frames.size(); b0 += (size_t)max_frames) {
+      const int nb = (int)std::min((size_t)max_frames, frames.size() - b0);
+      int stride = 0;
+      for (int i = 0; i < nb; i++) stride = std::max(stride, frames[b0 + i].length);
+      std::vector<int32_t> stage((size_t)nb * nch * stride, 0);
+      std::vector<int> ns(nb);
+      long long cap = 0;
+      for (int i = 0; i < nb; i++) {
+        const FrameRef &fr = frames[b0 + i];
+        ns[i] = fr.length;
+        for (int ch = 0; ch < nch; ch++)
+          std::memcpy(&stage[((size_t)i * nch + ch) * stride], pcm[fr.file].data() + (size_t)ch * wavs[fr.file].numsamples + fr.start, sizeof(int32_t) * (size_t)fr.length);
+        cap += (long long)fr.length * nch * 4 + 2 * 4096 + 70000;
+      }
+      chk(sacamd_frames_upload_i32(ctx, nb, maxfs, stage.data(), (long long)nch * stride, stride, ns.data()));
+      std::vector<float> prof((size_t)nb * SACAMD_NUM_COEFS), vmin(SACAMD_NUM_COEFS), vmax(SACAMD_NUM_COEFS), vdef(SACAMD_NUM_COEFS);
+      sacamd_default_profile(vmin.data(), vmax.data(), vdef.data());
+      for (int i = 0; i < nb; i++) std::copy(vdef.begin(), vdef.end(), prof.begin() + (size_t)i * SACAMD_NUM_COEFS);
+      std::vector<uint8_t> out((size_t)cap);
+      std::vector<long long> off(nb + 1);
+      chk(sacamd_encode_frames(ctx, &cfg, prof.data(), out.data(), cap, off.data()));
+      for (int i = 0; i < nb; i++) {
+        auto &dst = payload[frames[b0 + i].file];
+        dst.insert(dst.end(), out.begin() + off[i], out.begin() + off[i + 1]);
+        nfr[frames[b0 + i].file]++;
+      }
+    }
+    sacamd_ctx_destroy(ctx);
+
+    for (size_t f = 0; f < wavs.size(); f++) {
+      std::string op = outarg;
+      if (multi) {
+        std::string base = pos[f].substr(pos[f].find_last_of('/') == std::string::npos ? 0 : pos[f].find_last_of('/') + 1);
+        const size_t dot = base.find_last_of('.');
+        op = outarg + "/" + (dot == std::string::npos ? base : base.substr(0, dot)) + ".sac";
+      }
+      const std::vector<uint8_t> hdr = sac_header_and_md5(wavs[f], framelen);
+      std::ofstream o(op, std::ios::binary);
+      if (!o) throw std::runtime_error("cannot write " + op);
+      o.write((const char *)hdr.data(), (std::streamsize)hdr.size());
+      o.write((const char *)payload[f].data(), (std::streamsize)payload[f].size());
+      const double total = (double)hdr.size() + payload[f].size();
+      std::printf("%s: %d samples x %d ch, %d frames -> %.0f bytes, %.3f bps\n", pos[f].c_str(), wavs[f].numsamples, nch, nfr[f], total,
+                  8.0 * total / std::max(1.0, (double)wavs[f].numsamples * nch));
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << "sacenc: " << e.what() << "\n";
+    return 1;
+  }
+}

@@ -205,3 +205,20 @@ def test_sac_file_is_read_by_the_genuine_reference(orc, ref, tmp_path):
     assert np.array_equal(dec, pcm)
     h2, m2, chunks2, recs2 = C.read_sac(path)
     assert recs2 == recs and chunks2 == w.chunks and m2 == md5
+
+
+def test_cpp_container_header_matches_python(tmp_path):
+    """sacenc's C++ container layer (sacfile.h: WAV walk, metadata, SAC2 header, own MD5) writes the
+    same header + MD5 bytes as sac_amd.container (hashlib MD5) -- no device involved."""
+    from sac_amd import container as C
+    from sac_amd.synth import synth_pcm
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sac_amd", "sacenc")
+    assert os.path.exists(exe), "sac_amd/sacenc not built (make -C sac_amd/csrc)"
+    import hashlib
+    for seed, nch, n, bits, extra in ((1, 2, 1001, 16, [(0x5453494C, b"INFOISFT\x05\x00\x00\x00abcde")]), (2, 1, 777, 8, []), (3, 2, 64, 16, [(0x6B6E756A, b"xyz")])):
+        blob = C.wav_bytes_from_pcm(synth_pcm(n, nch, seed, 8000, bits=bits), 8000, bits, extra_chunks=extra)
+        wav = tmp_path / f"t{seed}.wav"; out = tmp_path / f"t{seed}.hdr"
+        wav.write_bytes(blob)
+        subprocess.run([exe, "--header-only", "--framelen=7", str(wav), str(out)], check=True)
+        w = C.parse_wav(blob)
+        assert out.read_bytes() == C.sac_header(w, 7) + hashlib.md5(w.data).digest()

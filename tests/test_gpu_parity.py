@@ -301,3 +301,27 @@ def test_wav_to_sac_file_end_to_end(api, orc, tmp_path):
         from oracle_api import Checker
         h, m, meta, d, nf = Checker("ref").read_sac(path)
         assert np.array_equal(d, pcm) and nf == len(recs) and m == md5 and meta == C.pack_metadata(info.chunks)
+
+
+def test_sacenc_cli_matches_python_driver(api, tmp_path):
+    """The C++ command-line encoder (sac_amd/sacenc: sacfile.h + C ABI) writes byte-identical .sac
+    files to the Python container/driver path for two files encoded as one batch."""
+    import os, subprocess
+    from sac_amd import container as C
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sac_amd", "sacenc")
+    rate, maxlen = RATE, 4
+    pcms = [synth_pcm(9 * rate + 77, 2, 404, rate) >> 3, synth_pcm(5 * rate, 2, 405, rate) >> 3]
+    pcms[0][:, 3 * rate: 6 * rate] = (pcms[0][:, 3 * rate: 6 * rate] // 16) * 16
+    blobs = [C.wav_bytes_from_pcm(p, rate, 16) for p in pcms]
+    outdir = tmp_path / "out"; outdir.mkdir()
+    names = []
+    for i, b in enumerate(blobs):
+        (tmp_path / f"in{i}.wav").write_bytes(b); names.append(str(tmp_path / f"in{i}.wav"))
+    subprocess.run([exe, "--high", "--opt-cfg=dds,4", f"--framelen={maxlen}", *names, str(outdir)], check=True)
+    ctx = api.Context(2, maxlen * rate, 16)
+    res = C.encode_wav_files(ctx, blobs, api.make_cfg("high", num_threads=4), max_framelen=maxlen)
+    ctx.close()
+    for i, (info, recs) in enumerate(res):
+        want = tmp_path / f"py{i}.sac"
+        C.write_sac(str(want), info, maxlen, recs)
+        assert (outdir / f"in{i}.sac").read_bytes() == want.read_bytes()
