@@ -76,7 +76,7 @@ struct DevBuf {
 
 enum { FAM_ANALYSE = 0, FAM_TABLES, FAM_OLS, FAM_LMS, FAM_BIAS, FAM_COST, FAM_S2U, FAM_CODER, FAM_COUNT };
 
-struct TimedSpan { int fam; hipEvent_t a, b; };
+struct TimedSpan { int fam; hipEvent_t a, b; bool shared_a = false; };   // shared_a: a belongs to another span
 // per-launch timing of one predictor kernel instance (events on the launch's own stream);
 // SACAMD_TRACE=1 additionally prints each launch on stderr
 struct TraceSpan { char label[64]; int kind, cls; double item_steps; hipEvent_t a, b; };
@@ -86,9 +86,9 @@ struct TraceSpan { char label[64]; int kind, cls; double item_steps; hipEvent_t 
 struct sacamd_ctx {
   int device = 0, nch = 0, max_framesize = 0, max_frames = 0;
   hipStream_t stream = nullptr;
-  static constexpr int kSide = 12;                 // side streams: concurrent launches of one stage
+  static constexpr int kSide = 20;                 // side streams: 8 OLS classes + cascade launches (GPU_MAX_HW_QUEUES=24)
   hipStream_t cls_stream[kSide] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {}, ev_ols[kNumOlsClasses] = {};
   std::string err;
   unsigned long long *d_prof = nullptr;   // debug: OLS section counters
   // staged batch
@@ -161,10 +161,13 @@ struct Span {
 };
 
 void collect_spans(sacamd_ctx *c) {
-  for (auto &s : c->spans) {
+  for (auto &s : c->spans) {                       // all elapsed times first: spans may share events
     float ms = 0;
-    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) c->fam_ms[s.fam] += ms;
-    (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess && ms > 0) c->fam_ms[s.fam] += ms;
+  }
+  for (auto &s : c->spans) {
+    if (!s.shared_a) (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
   }
   c->spans.clear();
   for (auto &t : c->trace) {
@@ -252,72 +255,92 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
   HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
-  // class lists, heaviest first
-  std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses];
-  for (int i = 0; i < count; i++) { idx_ols[items[i].ols_class].push_back(i); idx_lms[items[i].lms_class].push_back(i); }
+  // class lists, heaviest first.  Cascade items are additionally split by how long their OLS class
+  // runs (group 0: one-wave classes <= 32 taps, group 1: the panel classes): a cascade launch only
+  // waits for the OLS classes of its own group, so cascade work starts under the OLS tail.
+  constexpr int kFastOls = 3;                       // OLS classes [0, kFastOls) form group 0
+  std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][2];
+  for (int i = 0; i < count; i++) { idx_ols[items[i].ols_class].push_back(i); idx_lms[items[i].lms_class][items[i].ols_class >= kFastOls].push_back(i); }
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
   std::vector<int> flat;
-  int base_ols[kNumOlsClasses], base_lms[kNumLmsClasses];
+  int base_ols[kNumOlsClasses];
   for (int k = 0; k < kNumOlsClasses; k++) {
     std::stable_sort(idx_ols[k].begin(), idx_ols[k].end(), [&](int a, int b) { return olsw(a) > olsw(b); });
     base_ols[k] = (int)flat.size(); flat.insert(flat.end(), idx_ols[k].begin(), idx_ols[k].end());
   }
-  for (int k = 0; k < kNumLmsClasses; k++) {
-    std::stable_sort(idx_lms[k].begin(), idx_lms[k].end(), [&](int a, int b) { return taps(a) > taps(b); });
-    base_lms[k] = (int)flat.size(); flat.insert(flat.end(), idx_lms[k].begin(), idx_lms[k].end());
-  }
-  // Cascade launches: the history rings are sized for the taps in use.  Each class list (sorted by
-  // taps) is cut into tiers wherever the smaller footprint of the remaining items lets one more
+  // Cascade launches: the history rings are sized for the taps in use.  Each list (sorted by taps)
+  // is cut into tiers wherever the smaller footprint of the remaining items lets one more
   // workgroup fit on a CU (160 KB LDS); tiers are independent launches.
-  struct LmsLaunch { int cls, first, count; LmsRingCap rc; };
+  struct LmsLaunch { int cls, group, first, count; LmsRingCap rc; };
   std::vector<LmsLaunch> lms_launches;
-  for (int k = 0; k < kNumLmsClasses; k++) {
-    const std::vector<int> &v = idx_lms[k];
-    const int m = (int)v.size();
-    if (!m) continue;
-    std::vector<LmsRingCap> suf(m);
-    for (int i = m - 1; i >= 0; i--)
-      for (int q = 0; q < 4; q++) suf[i].c[q] = std::max(items[v[i]].p.vn[q] + 1, i + 1 < m ? suf[i + 1].c[q] : 0);
-    auto fit = [&](int i) { return std::min(lms_max_wg_per_cu(k), (int)(160 * 1024 / lms_lds_bytes(k, suf[i]))); };
-    int first = 0;
-    for (int i = 1; i <= m; i++) {
-      if (i == m || (fit(i) > fit(first) && i - first >= 64 && m - i >= 64)) {
-        lms_launches.push_back({k, base_lms[k] + first, i - first, suf[first]});
-        first = i;
+  for (int g = 0; g < 2; g++)
+    for (int k = 0; k < kNumLmsClasses; k++) {
+      std::vector<int> &v = idx_lms[k][g];
+      const int m = (int)v.size();
+      if (!m) continue;
+      std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return taps(a) > taps(b); });
+      const int base = (int)flat.size();
+      flat.insert(flat.end(), v.begin(), v.end());
+      std::vector<LmsRingCap> suf(m);
+      for (int i = m - 1; i >= 0; i--)
+        for (int q = 0; q < 4; q++) suf[i].c[q] = std::max(items[v[i]].p.vn[q] + 1, i + 1 < m ? suf[i + 1].c[q] : 0);
+      auto fit = [&](int i) { return std::min(lms_max_wg_per_cu(k), (int)(160 * 1024 / lms_lds_bytes(k, suf[i]))); };
+      int first = 0;
+      for (int i = 1; i <= m; i++) {
+        if (i == m || (fit(i) > fit(first) && i - first >= 64 && m - i >= 64)) {
+          lms_launches.push_back({k, g, base + first, i - first, suf[first]});
+          first = i;
+        }
       }
     }
-  }
+  HIPCHK(c, c->d_idx.ensure(flat.size() + 16));
   HIPCHK(c, hipMemcpyAsync(c->d_idx.p, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, c->stream));
   { Span sp(c, FAM_TABLES); launch_tables(c->stream, c->d_items.p, count, c->d_tab.p); }
-  // the launches of one stage are independent kernels: fork them onto side streams so that the
-  // (latency-bound, low-occupancy) launches overlap; the stage boundary is a join on the main stream
-  auto fork_join = [&](int nlaunch, auto &&launch_one) -> int {
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    const int used = std::min(nlaunch, (int)sacamd_ctx::kSide);
-    for (int k = 0; k < used; k++) HIPCHK(c, hipStreamWaitEvent(c->cls_stream[k], c->ev_fork, 0));
-    for (int k = 0; k < nlaunch; k++) launch_one(k, c->cls_stream[k % sacamd_ctx::kSide]);
-    for (int k = 0; k < used; k++) {
-      HIPCHK(c, hipEventRecord(c->ev_join[k], c->cls_stream[k]));
-      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
-    }
-    return 0;
-  };
-  { Span sp(c, FAM_OLS);
-    // heaviest class first: its items are the long pole of the stage
-    int r = fork_join(kNumOlsClasses, [&](int q, hipStream_t st) {
-      const int k = kNumOlsClasses - 1 - q;
+  // Launch graph: fork -> OLS class k on side stream k (event ev_ols[k]) ; cascade launch q on side
+  // stream 8 + q % 11, after the OLS events of its group ; the last side stream only marks "all OLS
+  // done" for the timing spans ; the main stream joins everything before the bias stage.
+  TimedSpan sp_ols{FAM_OLS, nullptr, nullptr}, sp_lms{FAM_LMS, nullptr, nullptr};
+  HIPCHK(c, hipEventCreate(&sp_ols.a)); HIPCHK(c, hipEventCreate(&sp_ols.b)); HIPCHK(c, hipEventCreate(&sp_lms.b));
+  HIPCHK(c, hipEventRecord(sp_ols.a, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  constexpr int kMark = sacamd_ctx::kSide - 1, kLmsStreams = sacamd_ctx::kSide - 1 - kNumOlsClasses;
+  HIPCHK(c, hipStreamWaitEvent(c->cls_stream[kMark], c->ev_fork, 0));
+  for (int q = 0; q < kNumOlsClasses; q++) {
+    const int k = kNumOlsClasses - 1 - q;            // heaviest class first: its items are the long pole
+    if (idx_ols[k].empty()) continue;
+    hipStream_t st = c->cls_stream[k];
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
+    {
       double isteps = 0; for (int i : idx_ols[k]) isteps += items[i].n;
       Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps);
-      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p); });
-    if (r) return r; }
-  { Span sp(c, FAM_LMS);
-    int r = fork_join((int)lms_launches.size(), [&](int q, hipStream_t st) {
-      const LmsLaunch &ll = lms_launches[q];
-      double isteps = 0; for (int i = 0; i < ll.count; i++) isteps += items[flat[ll.first + i]].n;
-      Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps);
-      launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p); });
-    if (r) return r; }
+      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
+    HIPCHK(c, hipStreamWaitEvent(c->cls_stream[kMark], c->ev_ols[k], 0));
+  }
+  HIPCHK(c, hipEventRecord(sp_ols.b, c->cls_stream[kMark]));
+  HIPCHK(c, hipEventRecord(c->ev_join[kMark], c->cls_stream[kMark]));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[kMark], 0));
+  bool lms_used[sacamd_ctx::kSide] = {};
+  for (size_t q = 0; q < lms_launches.size(); q++) {
+    const LmsLaunch &ll = lms_launches[q];
+    const int si = kNumOlsClasses + (int)(q % kLmsStreams);
+    hipStream_t st = c->cls_stream[si];
+    if (!lms_used[si]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); lms_used[si] = true; }
+    for (int k = ll.group ? kFastOls : 0; k < (ll.group ? kNumOlsClasses : kFastOls); k++)
+      if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
+    double isteps = 0; for (int i = 0; i < ll.count; i++) isteps += items[flat[ll.first + i]].n;
+    Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps);
+    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p);
+  }
+  for (int si = kNumOlsClasses; si < kMark; si++)
+    if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], c->cls_stream[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
+  HIPCHK(c, hipEventRecord(sp_lms.b, c->stream));
+  sp_lms.a = sp_ols.b;                               // cascade span = what is left after the last OLS kernel ended
+  sp_lms.shared_a = true;
+  c->spans.push_back(sp_ols); c->spans.push_back(sp_lms);
+  c->fam_launches[FAM_OLS]++; c->fam_launches[FAM_LMS]++;
   { Span sp(c, FAM_BIAS);
     launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
   HIPCHK(c, hipGetLastError());
@@ -371,6 +394,8 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
     if (hipStreamCreate(&c->cls_stream[k]) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
+  for (int k = 0; k < kNumOlsClasses; k++)
+    if (hipEventCreateWithFlags(&c->ev_ols[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   c->ch_stride = ((long long)max_framesize + 63) / 64 * 64;
   c->frame_stride = c->ch_stride * nch;
   const size_t tot = (size_t)c->frame_stride * max_frames;
@@ -388,6 +413,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); (void)hipStreamDestroy(c->stream); }
   for (int k = 0; k < sacamd_ctx::kSide; k++) { if (c->cls_stream[k]) (void)hipStreamDestroy(c->cls_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
+  for (int k = 0; k < kNumOlsClasses; k++) if (c->ev_ols[k]) (void)hipEventDestroy(c->ev_ols[k]);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
