@@ -55,6 +55,7 @@ struct LmsLds {
   double *pv;                // stage predictions p[0..4]
   double *exwm;              // expert weights mirror [2][5]
   double *cst;               // vmu[4], sum_powtab[4]
+  double *hs;                // head -> pieces: target, ep[2], pl[5], bp4, rpx, -, -; [12..13] blend weights smw
   double *libm;              // staged log/exp tables of libm_port.h
   int *sv;
   // ringcap[s] >= vn[s] + 1 of every work-item of the launch (<= C::slots(s) * NL + 1): the LDS
@@ -62,7 +63,7 @@ struct LmsLds {
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
     for (int s = 0; s < 4; s++) d += (size_t)ringcap[s];
-    d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + 8 + 10 + 8 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
+    d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + NL * sizeof(int) + 16;
   }
   SA_HD static size_t bytes() {
@@ -76,7 +77,7 @@ struct LmsLds {
     bc = d; d += 8;
     pin = d; d += NL; pout = d; d += NL;
     rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
-    pv = d; d += 8; exwm = d; d += 10; cst = d; d += 8;
+    pv = d; d += 8; exwm = d; d += 10; cst = d; d += 8; hs = d; d += 16;
     libm = d; d += kLibmLdsDoubles;
     sv = reinterpret_cast<int *>(d);
   }
@@ -124,14 +125,16 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
 #pragma unroll
     for (int s = 0; s < 4; s++) if (l == s) { L.cst[s] = p.vmu[s]; L.cst[4 + s] = sum_powtab[s]; }
     if (l < 10) L.exwm[l] = 1.0 / 5;
+    if (l < 16) L.hs[l] = (l == 12 || l == 13) ? 0.5 : 0.0;
     if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }
     exw_r[l] = 1.0 / 5; exeg_r[l] = 0.0; rw_r[l] = 0.0; ph_r[l] = 0.0; xo_r[l] = 0.0; dots_r[l] = 0.0; spow_r[l] = 0.0; rcp_r[l] = 0.0; exz_r[l] = 0.0;
-    for (int j = 0; j < kRlsMax; j++) Prow[l].v[j] = (j == l) ? 1.0 : 0.0;
+    for (int j = 0; j < kRlsMax; j++) Prow[l].v[j] = (j == (l & 63)) ? 1.0 : 0.0;   // identity rows on the lanes of every wave (wave 2 owns P)
   });
   ex.sync();
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
   // uniform mixer state (wave 0)
-  double smw[2] = {0.5, 0.5}, smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0;
+  double smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0, denom = 0.0, inv_alpha = 0.0;   // wave 3 / wave 2 uniform state
+  bool have_prev = false;
 
   const double lo = (double)p.lo, hi = (double)p.hi;
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
@@ -182,8 +185,23 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       });
       ex.sync();
       SA_TICK(2);
-      // ---- B: mixer chain on wave 0, lane-parallel where the algebra allows
-      ex.leader_par([&](int l) {
+      // ---- B: mixer chain.  Wave 0 turns the stage sums into the prediction and the stage gains;
+      // after one barrier the three updates that only feed the NEXT prediction run side by side on
+      // waves 1..3 (each then goes straight on to its share of the next sweep):
+      //   wave 1  LS_ADA expert weights            wave 2  RLS / ALC            wave 3  BlendExp softmax
+      // The RLS P-matrix update is deferred until after the next sweep's barrier, where it hides
+      // under wave 0's work.
+      if (have_prev) {
+        ex.wave_par(2, [&](int g) {   // P update of row l (rls.cpp:47-56) of the PREVIOUS step
+          const int l = g & 63;
+          if (l < m) {
+#pragma unroll
+            for (int j = 0; j < kRlsMax; j++)
+              if (j < m) Prow[g].v[j] = fma(-denom, ph_r[g] * L.rph[j], Prow[g].v[j]) * inv_alpha;
+          }
+        });
+      }
+      ex.wave_par(0, [&](int l) {
         if (l >= 16 && l < 20) {   // cross-wave totals of stage l-16, waves in order (lanes 16..19 own the stage gains)
           const int s = l - 16;
           double a = L.part[(par * NW) * 8 + s], b = L.part[(par * NW) * 8 + 4 + s];
@@ -192,72 +210,79 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         }
       });
       ex.wsync();
-      double target = 0.0, rpx = 0.0, ep[2] = {0, 0}, pred = 0.0, bp[5] = {0, 0, 0, 0, 0}, pl[5] = {0, 0, 0, 0, 0};
-      ex.leader([&]() {
+      double bp[5] = {0, 0, 0, 0, 0};
+      ex.wave(0, [&]() {
         const double plpc = L.pin[tt];
-        target = (double)L.sv[tt] - plpc;
+        const double target = (double)L.sv[tt] - plpc;
+        const double smw0 = L.hs[12], smw1 = L.hs[13];
         // Cascade::Predict (cascade.h:93-100)
-        rpx = dot_canon(L.rx, L.rw, m);
+        const double rpx = dot_canon(L.rx, L.rw, m);
+        double pl[5], ep[2];
         for (int i = 0; i < 4; i++) pl[i] = L.pv[i];
         pl[4] = rpx;
         for (int e = 0; e < 2; e++) ep[e] = dot_canon_n<5>([&](int i) { return pl[i]; }, [&](int i) { return L.exwm[5 * e + i]; });
-        pred = dot_canon_n<2>([&](int i) { return i ? ep[1] : ep[0]; }, [&](int i) { return i ? smw[1] : smw[0]; });
+        const double pred = dot_canon_n<2>([&](int i) { return i ? ep[1] : ep[0]; }, [&](int i) { return i ? smw1 : smw0; });
         L.pout[tt] = plpc + pred;
         // Cascade::Update(target): stage targets (cascade.h:101-112)
         double p_prefix = 0.0;
 #pragma unroll
         for (int i = 0; i <= 4; i++) {
           const double ew0 = L.exwm[i], ew1 = L.exwm[5 + i];
-          const double wgt = fmax(dot_canon_n<2>([&](int q) { return q ? ew1 : ew0; }, [&](int q) { return q ? smw[1] : smw[0]; }), 0.0);
+          const double wgt = fmax(dot_canon_n<2>([&](int q) { return q ? ew1 : ew0; }, [&](int q) { return q ? smw1 : smw0; }), 0.0);
           const double px = fma(1.0 - p.proj_alpha, p_prefix, p.proj_alpha * pred);
           bp[i] = target - clampd(px, lo, hi);
           p_prefix = fma(wgt, pl[i], p_prefix);
         }
+        if (E::is_lane0()) {   // hand-over to the update waves
+          L.hs[0] = target; L.hs[1] = ep[0]; L.hs[2] = ep[1];
+          for (int i = 0; i < 5; i++) L.hs[3 + i] = pl[i];
+          L.hs[8] = bp[4]; L.hs[9] = rpx;
+        }
       });
       SA_TICK(3);
-      ex.leader_par([&](int l) {
-        // lanes 16..19: NLMS_Stream::Update scalar part (ls.h:47-48) + history push of stage l-16;
-        // lanes 0..9: LS_ADA experts (ls.h:224-236), expert e = l/5 (0: L1 loss, 1: L2), input i = l%5.
-        // Both end in one division, issued once for all of them.
-        const bool isg = l >= 16 && l < 20, ise = l < 10;
-        const int sl = l - 16;
-        double num = 0.0, den = 1.0, grad = 0.0, bps = 0.0;
-        if (isg) {
-          bps = sl == 0 ? bp[0] : (sl == 1 ? bp[1] : (sl == 2 ? bp[2] : bp[3]));
-          num = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl];
-          den = spow_r[l] + 1.0;
-        }
-        if (ise) {
-          const int e = l >= 5, i = l - 5 * e;
-          const double error = target - (e ? ep[1] : ep[0]);
-          const double loss = e ? error : sgnd(error);
-          const double pi_ = i == 0 ? pl[0] : (i == 1 ? pl[1] : (i == 2 ? pl[2] : (i == 3 ? pl[3] : pl[4])));
-          grad = loss * pi_;
-          const double beta = p.mu_mix_beta, beta1 = 1.0 - p.mu_mix_beta;
-          exeg_r[l] = fma(beta, exeg_r[l], beta1 * grad * grad);
-          num = p.mu_mix;
-          den = sqrt(exeg_r[l]) + 1e-5;
-        }
-        const double quo = num / den;
-        if (ise) exw_r[l] = fma(quo, grad, exw_r[l]);
-        if (isg) {
+      ex.wave_par(0, [&](int l) {
+        // lanes 16..19: NLMS_Stream::Update scalar part (ls.h:47-48) + history push of stage l-16
+        if (l >= 16 && l < 20) {
+          const int sl = l - 16;
+          const double bps = sl == 0 ? bp[0] : (sl == 1 ? bp[1] : (sl == 2 ? bp[2] : bp[3]));
           const int ps = sl == 0 ? pos[0] : (sl == 1 ? pos[1] : (sl == 2 ? pos[2] : pos[3]));
           const int cs = sl == 0 ? cap[0] : (sl == 1 ? cap[1] : (sl == 2 ? cap[2] : cap[3]));
           double *rg = sl == 0 ? L.ring[0] : (sl == 1 ? L.ring[1] : (sl == 2 ? L.ring[2] : L.ring[3]));
-          L.bc[sl] = quo;
+          L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
           int np = ps - 1; if (np < 0) np += cs;
           rg[np] = bps;
         }
-        if (l < m) {   // RLS: ph = P x, row l (rls.cpp:33)
-          ph_r[l] = dot_canon_m(m, [&](int j) { return Prow[l].v[j]; }, [&](int j) { return L.rx[j]; });
-          L.rph[l] = ph_r[l];
+      });
+      SA_TICK(4);
+      ex.sync();
+      SA_TICK(5);
+      // ---- wave 1: LS_ADA experts (ls.h:224-236), lanes 0..9: expert e = l/5 (0: L1 loss, 1: L2), input i = l%5
+      ex.wave_par(1, [&](int g) {
+        const int l = g & 63;
+        if (l < 10) {
+          const int e = l >= 5, i = l - 5 * e;
+          const double error = L.hs[0] - L.hs[1 + e];
+          const double loss = e ? error : sgnd(error);
+          const double grad = loss * L.hs[3 + i];
+          const double beta = p.mu_mix_beta, beta1 = 1.0 - p.mu_mix_beta;
+          exeg_r[g] = fma(beta, exeg_r[g], beta1 * grad * grad);
+          const double mu_scaled = p.mu_mix / (sqrt(exeg_r[g]) + 1e-5);
+          exw_r[g] = fma(mu_scaled, grad, exw_r[g]);
+          L.exwm[l] = exw_r[g];
+        }
+      });
+      // ---- wave 2: RLS::Update + ALC (rls.cpp:28-56, rls.h:21-39) except the P update (deferred)
+      ex.wave_par(2, [&](int g) {
+        const int l = g & 63;
+        if (l < m) {   // ph = P x, row l (rls.cpp:33)
+          ph_r[g] = dot_canon_m(m, [&](int j) { return Prow[g].v[j]; }, [&](int j) { return L.rx[j]; });
+          L.rph[l] = ph_r[g];
         }
       });
       ex.wsync();
-      SA_TICK(4);
-      double denom = 0.0, inv_alpha = 0.0, rerr = 0.0, alpha = 0.0, phi = 0.0, zm[2] = {0, 0}, maxz = 0.0;
-      ex.leader([&]() {   // RLS::Update scalars + ALC (rls.cpp:28-46, rls.h:21-39)
-        rerr = bp[4] - rpx;
+      double rerr = 0.0, alpha = 0.0, phi = 0.0;
+      ex.wave(2, [&]() {
+        rerr = L.hs[8] - L.hs[9];
         phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8);
         const double err2 = rerr * rerr;
         const double R = fmax(S0 - S1, 1e-5);
@@ -266,45 +291,42 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         alpha = fma(0.999 - 0.99, mm, 0.99);
         S0 = fma(0.95, S0, (1.0 - 0.95) * err2);
         S1 = fma(0.95, S1, (1.0 - 0.95) * phi);
-        // BlendExp<RunSumEMA>::Update (blend.h:31-90)
+      });
+      ex.wave_par(2, [&](int g) { if ((g & 63) < 2) rcp_r[g] = 1.0 / ((g & 63) == 0 ? alpha + phi : alpha); });   // both reciprocals in one instruction stream
+      ex.wave(2, [&]() { denom = ex.lane_bcast(rcp_r, 128); inv_alpha = ex.lane_bcast(rcp_r, 129); });
+      ex.wave_par(2, [&](int g) {
+        const int l = g & 63;
+        if (l < m) {
+          rw_r[g] = fma(rerr, denom * ph_r[g], rw_r[g]);
+          xo_r[g] = l > 0 ? L.rx[l - 1] : 0.0;
+        }
+      });
+      ex.wsync();
+      ex.wave_par(2, [&](int g) {
+        const int l = g & 63;
+        if (l < m) { L.rw[l] = rw_r[g]; L.rx[l] = l == 0 ? L.hs[8] : xo_r[g]; }   // RollBack(x, val), rls.cpp:64
+      });
+      // ---- wave 3: BlendExp<RunSumEMA>::Update (blend.h:31-90)
+      double zm[2] = {0, 0}, maxz = 0.0;
+      ex.wave(3, [&]() {
         for (int e = 0; e < 2; e++) {
-          const double loss = fabs(target - ep[e]);
+          const double loss = fabs(L.hs[0] - L.hs[1 + e]);
           smrs[e] = fma(0.95, smrs[e], (1.0 - 0.95) * (-loss));
           zm[e] = 1.0 * smrs[e];
         }
         maxz = fmax(zm[0], zm[1]);
       });
-      // independent reciprocals / exponentials: one instruction stream, lanes 0 and 1
-      ex.leader_par([&](int l) {
-        if (l < 2) {
-          rcp_r[l] = 1.0 / (l == 0 ? alpha + phi : alpha);
-          exz_r[l] = sa_exp_t((l == 0 ? zm[0] : zm[1]) - maxz, exptab);
-        }
-      });
-      ex.leader([&]() {
-        denom = ex.lane_bcast(rcp_r, 0); inv_alpha = ex.lane_bcast(rcp_r, 1);
-        const double w0 = ex.lane_bcast(exz_r, 0), w1 = ex.lane_bcast(exz_r, 1);
+      ex.wave_par(3, [&](int g) { if ((g & 63) < 2) exz_r[g] = sa_exp_t(((g & 63) == 0 ? zm[0] : zm[1]) - maxz, exptab); });
+      ex.wave(3, [&]() {
+        const double w0 = ex.lane_bcast(exz_r, 192), w1 = ex.lane_bcast(exz_r, 193);
         const double inv = 1.0 / (w0 + w1);
-        smw[0] = w0 * inv; smw[1] = w1 * inv;
+        if (E::is_lane0w()) { L.hs[12] = w0 * inv; L.hs[13] = w1 * inv; }
       });
-      SA_TICK(5);
-      ex.leader_par([&](int l) {
-        if (l < 10) L.exwm[l] = exw_r[l];
-        if (l < m) {   // P / w update of row l (rls.cpp:47-56); both triangles get the same bits
-#pragma unroll
-          for (int j = 0; j < kRlsMax; j++)
-            if (j < m) Prow[l].v[j] = fma(-denom, ph_r[l] * L.rph[j], Prow[l].v[j]) * inv_alpha;
-          rw_r[l] = fma(rerr, denom * ph_r[l], rw_r[l]);
-          xo_r[l] = l > 0 ? L.rx[l - 1] : 0.0;
-        }
-      });
-      ex.wsync();
-      ex.leader_par([&](int l) {
-        if (l < m) { L.rw[l] = rw_r[l]; L.rx[l] = l == 0 ? bp[4] : xo_r[l]; }   // RollBack(x, val), rls.cpp:64
-      });
+      have_prev = true;
       for (int s = 0; s < 4; s++) { pos[s] -= 1; if (pos[s] < 0) pos[s] += cap[s]; }
       SA_TICK(6);
-      ex.sync();
+      // (no barrier here: the next sweep only needs what wave 0 published before the barrier above;
+      //  everything waves 1..3 just wrote is consumed after the next sweep's barrier)
       SA_TICK(7);
     }
   }

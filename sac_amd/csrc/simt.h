@@ -57,8 +57,13 @@ struct ExecEmu {
   static unsigned long long clock() { return 0; }
   static bool is_lane0() { return true; }     // inside uni(): the single emulated instance stands for lane 0
   static bool is_leader() { return true; }    // top-level code of wave 0 (the emulator runs top-level code once)
+  static bool is_lane0w() { return true; }    // inside wave(): lane 0 of that wave
   // per-lane code of wave 0 only; wsync orders LDS traffic inside one wave
   template <class F> void leader_par(F &&f) { for (int l = 0; l < (NL < 64 ? NL : 64); l++) f(l); }
+  // uniform code / per-lane code of wave w only; the lane index handed to f is the workgroup-wide
+  // one (64*w + lane) so that registers are addressed the same way everywhere
+  template <class F> void wave(int, F &&f) { f(); }
+  template <class F> void wave_par(int w, F &&f) { for (int l = 0; l < 64; l++) f(64 * w + l); }
   void wsync() {}
   // butterfly sum of K values per lane within each 64-lane wave (all lanes get the wave total)
   template <int K, class R> void wave_sum(R &r) {
@@ -174,12 +179,15 @@ struct ExecDev {
   static SA_D unsigned long long clock() { return __builtin_readcyclecounter(); }
   static SA_D bool is_lane0() { return threadIdx.x == 0; }
   static SA_D bool is_leader() { return threadIdx.x < 64; }
+  static SA_D bool is_lane0w() { return (threadIdx.x & 63) == 0; }
   template <class F> SA_D void leader_par(F &&f) { if (threadIdx.x < 64) f((int)threadIdx.x); }
+  template <class F> SA_D void wave(int w, F &&f) { if ((int)(threadIdx.x >> 6) == w) f(); }
+  template <class F> SA_D void wave_par(int w, F &&f) { if ((int)(threadIdx.x >> 6) == w) f((int)threadIdx.x); }
   SA_D void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
   // value of lane k (k uniform across the wave) -> scalar broadcast via v_readlane_b32
   SA_D double lane_bcast(const Reg<double> &r, int k) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(r.v), k);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(r.v), k);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(r.v), k & 63);   // k may be a workgroup-wide lane index
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(r.v), k & 63);
     return __hiloint2double(hi, lo);
   }
   SA_D void allsum(Reg<double> &r, double *scratch) {
