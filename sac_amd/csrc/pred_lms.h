@@ -55,7 +55,7 @@ struct LmsLds {
   double *pv;                // stage predictions p[0..4]
   double *exwm;              // expert weights mirror [2][5]
   double *cst;               // vmu[4], sum_powtab[4]
-  double *hs;                // head -> pieces: target, ep[2], pl[5], bp4, rpx, -, -; [12..13] blend weights smw
+  double *hs;                // head -> pieces: target, ep[2], pl[5], bp4, rpx; [10] next RLS prediction (wave 2 -> head); [12..13] blend weights smw
   double *libm;              // staged log/exp tables of libm_port.h
   int *sv;
   // ringcap[s] >= vn[s] + 1 of every work-item of the launch (<= C::slots(s) * NL + 1): the LDS
@@ -133,7 +133,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   ex.sync();
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
   // uniform mixer state (wave 0)
-  double smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0, denom = 0.0, inv_alpha = 0.0;   // wave 3 / wave 2 uniform state
+  double smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0, denom = 0.0, inv_alpha = 0.0, phi = 0.0;   // wave 3 / wave 2 uniform state
   bool have_prev = false;
 
   const double lo = (double)p.lo, hi = (double)p.hi;
@@ -201,6 +201,15 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           }
         });
       }
+      ex.wave_par(2, [&](int g) {
+        const int l = g & 63;
+        if (l < m) {   // ph = P x, row l (rls.cpp:33): needs only P and the RLS history, both final by now
+          ph_r[g] = dot_canon_m(m, [&](int j) { return Prow[g].v[j]; }, [&](int j) { return L.rx[j]; });
+          L.rph[l] = ph_r[g];
+        }
+      });
+      ex.wsync();
+      ex.wave(2, [&]() { phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8); });
       ex.wave_par(0, [&](int l) {
         if (l >= 16 && l < 20) {   // cross-wave totals of stage l-16, waves in order (lanes 16..19 own the stage gains)
           const int s = l - 16;
@@ -216,7 +225,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         const double target = (double)L.sv[tt] - plpc;
         const double smw0 = L.hs[12], smw1 = L.hs[13];
         // Cascade::Predict (cascade.h:93-100)
-        const double rpx = dot_canon(L.rx, L.rw, m);
+        const double rpx = L.hs[10];                       // dot(rx, rw), left here by wave 2 after its update
         double pl[5], ep[2];
         for (int i = 0; i < 4; i++) pl[i] = L.pv[i];
         pl[4] = rpx;
@@ -271,19 +280,11 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           L.exwm[l] = exw_r[g];
         }
       });
-      // ---- wave 2: RLS::Update + ALC (rls.cpp:28-56, rls.h:21-39) except the P update (deferred)
-      ex.wave_par(2, [&](int g) {
-        const int l = g & 63;
-        if (l < m) {   // ph = P x, row l (rls.cpp:33)
-          ph_r[g] = dot_canon_m(m, [&](int j) { return Prow[g].v[j]; }, [&](int j) { return L.rx[j]; });
-          L.rph[l] = ph_r[g];
-        }
-      });
-      ex.wsync();
-      double rerr = 0.0, alpha = 0.0, phi = 0.0;
+      // ---- wave 2: RLS::Update + ALC (rls.cpp:28-56, rls.h:21-39) except the P update (deferred);
+      // ph = P x and phi were computed before the barrier (they do not depend on this step's prediction)
+      double rerr = 0.0, alpha = 0.0;
       ex.wave(2, [&]() {
         rerr = L.hs[8] - L.hs[9];
-        phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8);
         const double err2 = rerr * rerr;
         const double R = fmax(S0 - S1, 1e-5);
         const double nis = err2 / (phi + R);
@@ -305,6 +306,11 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       ex.wave_par(2, [&](int g) {
         const int l = g & 63;
         if (l < m) { L.rw[l] = rw_r[g]; L.rx[l] = l == 0 ? L.hs[8] : xo_r[g]; }   // RollBack(x, val), rls.cpp:64
+      });
+      ex.wsync();
+      ex.wave(2, [&]() {   // RLS::Predict of the NEXT step (rls.cpp:21-26): its inputs are final now
+        const double rpx_next = dot_canon(L.rx, L.rw, m);
+        if (E::is_lane0w()) L.hs[10] = rpx_next;
       });
       // ---- wave 3: BlendExp<RunSumEMA>::Update (blend.h:31-90)
       double zm[2] = {0, 0}, maxz = 0.0;
