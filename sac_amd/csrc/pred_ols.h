@@ -217,6 +217,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       bool ok = true;
       double dprev = 0.0, invd_prev = 0.0;
       int oj = 0;                                   // tri_off(no, j)
+      ex.par([&](int l) { sreg[l] = breg[l]; });    // forward substitution starts from b
       // Column j's stored-column terms k = 0 .. j-2 run as whole 8-term chunks.  D[k] is published
       // one column late (D[j-1] in column j's finish phase) and D is cleared first, so the chunk
       // terms k >= j-1 multiply by D[k] == 0 and leave the chain untouched; no tail masks.
@@ -264,12 +265,17 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
           acc[l] = s_;
         });
         if (j > 0) {
-          // finish column j-1: L[i][j-1] = lij * invD (math.h:49); its last term for column j
+          // finish column j-1: L[i][j-1] = lij * invD (math.h:49); its last term for column j.
+          // The forward substitution L y = b rides along: step j-1 of its column sweep needs exactly
+          // this column (still in registers) and y[j-1], which is final by now (math.h:58-66).
+          const double yk = ex.lane_bcast(sreg, j - 1);
           ex.par([&](int l) {
             const double lp = accprev[l] * invd_prev;
             accprev[l] = lp;
             if (l > j - 1 && l < no) L.Lq[(j - 1) * S + l] = lp;
             if (l == 0) L.Dv[j - 1] = dprev;
+            const double v = fold_fused(j - 1, l) ? fma(-lp, yk, sreg[l]) : sreg[l] - lp * yk;
+            if (l > j - 1 && l < no) sreg[l] = v;
           });
           const double bj = ex.lane_bcast(accprev, j);
           const bool fz = fold_fused(j - 1, j);
@@ -291,28 +297,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       }
       SA_TICK(2);
       if (ok) {
-        // forward solve: column sweep with register broadcasts
-        ex.par([&](int l) { sreg[l] = breg[l]; });
-#pragma unroll 1
-        for (int k0 = 0; k0 + 1 < no; k0 += 4) {
-          typename E::template Reg<DArr4> lv;
-          ex.par([&](int l) {
-            const int li = l < S ? l : S - 1;
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int kk = k0 + u < NMAX ? k0 + u : NMAX - 1; lv[l].v[u] = L.Lq[kk * S + li]; }
-          });
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int kk = k0 + u;
-            if (kk + 1 < no) {
-              const double yk = ex.lane_bcast(sreg, kk);
-              ex.par([&](int l) {
-                const double v = fold_fused(kk, l) ? fma(-lv[l].v[u], yk, sreg[l]) : sreg[l] - lv[l].v[u] * yk;
-                if (l > kk && l < no) sreg[l] = v;
-              });
-            }
-          }
-        }
+        // (the forward substitution was carried along by the factorisation)
         ex.par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
         SA_TICK(3);
         // backward solve: row i is the fused chain z_i - L[i+1][i] w[i+1] - ... in that order
@@ -463,6 +448,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
       });
       ex.sync();                                   // M complete, D cleared
       bool ok = true;
+      ex.leader_par([&](int l) { sreg[l] = breg[l]; });   // forward substitution starts from b
       for (int p4 = 0; p4 < no; p4 += PW) {
         const int nchunk = (p4 + 7) >> 3;           // chunks cover k < 8*nchunk <= NMAX; k >= p4 is masked by D == 0
         ex.par([&](int l) {
@@ -522,12 +508,15 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
             const double dj = ex.lane_bcast(accc, j);
             if (dj < 1e-12) { ok = false; break; }
             const double invd = 1.0 / dj;
+            const double yk = ex.lane_bcast(sreg, j);      // forward substitution rides along (see ols_stage_fast)
             ex.leader_par([&](int l) {
               const double v = accc[l] * invd;
               lpc[l] = v;
               if (l > j && l < no) L.Lq[j * S + l] = v;
               if (l == j) invd_mine[l] = invd;
               if (l == 0) L.Dv[j] = dj;
+              const double f = fold_fused(j, l) ? fma(-v, yk, sreg[l]) : sreg[l] - v * yk;
+              if (l > j && l < no) sreg[l] = f;
             });
             // term k = j of the later columns of this panel (their next term in ascending k)
 #pragma unroll
@@ -550,27 +539,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
       }
       SA_TICK(2);
       if (ok && E::is_leader()) {
-        // forward solve: column sweep with register broadcasts (wave 0)
-        ex.leader_par([&](int l) { sreg[l] = breg[l]; });
-#pragma unroll 1
-        for (int k0 = 0; k0 + 1 < no; k0 += 4) {
-          typename E::template Reg<DArr4> lv;
-          ex.leader_par([&](int l) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int kk = k0 + u < NMAX ? k0 + u : NMAX - 1; lv[l].v[u] = L.Lq[kk * S + l]; }
-          });
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int kk = k0 + u;
-            if (kk + 1 < no) {
-              const double yk = ex.lane_bcast(sreg, kk);
-              ex.leader_par([&](int l) {
-                const double v = fold_fused(kk, l) ? fma(-lv[l].v[u], yk, sreg[l]) : sreg[l] - lv[l].v[u] * yk;
-                if (l > kk && l < no) sreg[l] = v;
-              });
-            }
-          }
-        }
+        // (the forward substitution was carried along by the factorisation)
         ex.leader_par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
         SA_TICK(3);
         ex.leader_par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS (D is no longer needed)
@@ -715,6 +684,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
       });
       ex.sync();                                   // M complete, D cleared
       bool ok = true;
+      ex.leader_par([&](int l) { sreg[l].v[0] = breg[l].v[0]; sreg[l].v[1] = breg[l].v[1]; });   // forward substitution starts from b
       for (int p4 = 0; p4 < no; p4 += PW) {
         const int nchunk = (p4 + 7) >> 3;           // chunks cover k < 8*nchunk <= NMAX; k >= p4 is masked by D == 0
         ex.par([&](int l) {
@@ -780,6 +750,8 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
             const double dj = ex.lane_bcast(tmpb, lj);
             if (dj < 1e-12) { ok = false; break; }
             const double invd = 1.0 / dj;
+            ex.leader_par([&](int l) { tmpb[l] = hj ? sreg[l].v[1] : sreg[l].v[0]; });
+            const double yk = ex.lane_bcast(tmpb, lj);     // forward substitution rides along (see ols_stage_fast)
             ex.leader_par([&](int l) {
 #pragma unroll
               for (int h = 0; h < 2; h++) {
@@ -788,6 +760,8 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
                 lpc[l].v[h] = v;
                 if (row > j && row < no) L.Lq[j * S + row] = v;
                 if (row == j) invd_mine[l].v[h] = invd;
+                const double f = fold_fused(j, row) ? fma(-v, yk, sreg[l].v[h]) : sreg[l].v[h] - v * yk;
+                if (row > j && row < no) sreg[l].v[h] = f;
               }
               if (l == 0) L.Dv[j] = dj;
             });
@@ -816,23 +790,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
       }
       SA_TICK(2);
       if (ok && E::is_leader()) {
-        // forward solve: column sweep with register broadcasts (wave 0)
-        ex.leader_par([&](int l) { sreg[l].v[0] = breg[l].v[0]; sreg[l].v[1] = breg[l].v[1]; });
-#pragma unroll 1
-        for (int kk = 0; kk + 1 < no; kk++) {
-          const int hk = kk >> 6;
-          ex.leader_par([&](int l) { tmpb[l] = hk ? sreg[l].v[1] : sreg[l].v[0]; });
-          const double yk = ex.lane_bcast(tmpb, kk & 63);
-          ex.leader_par([&](int l) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-              const int row = l + 64 * h;
-              const double lv = L.Lq[kk * S + (row < S ? row : S - 1)];
-              const double v = fold_fused(kk, row) ? fma(-lv, yk, sreg[l].v[h]) : sreg[l].v[h] - lv * yk;
-              if (row > kk && row < no) sreg[l].v[h] = v;
-            }
-          });
-        }
+        // (the forward substitution was carried along by the factorisation)
         ex.leader_par([&](int l) { zreg[l].v[0] = sreg[l].v[0] * invd_mine[l].v[0]; zreg[l].v[1] = sreg[l].v[1] * invd_mine[l].v[1]; });
         SA_TICK(3);
         ex.leader_par([&](int l) {
