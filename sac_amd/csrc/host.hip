@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <numeric>
+#include <tuple>
 #include <random>
 #include <string>
 #include <vector>
@@ -108,7 +110,7 @@ struct sacamd_ctx {
   // predictor scratch
   DevBuf<WorkItem> d_items;
   DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist;
-  DevBuf<double> d_tab, d_p, d_cost;
+  DevBuf<double> d_tab, d_p, d_q, d_cost;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
   DevBuf<long long> d_off;
   // final pass products (per frame, channel): offsets (f*nch+ch)*ch_stride
   DevBuf<int> d_ferr, d_fpred, d_fs2u, d_fs2u_map, d_maxbpn;
@@ -231,7 +233,7 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
       const int *vn = p.vn;
       it.lms_class = (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) ? 0
                    : (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) ? 1 : 2;
-      it.off_p = off_p; it.off_err = off_p; it.off_tab = off_tab;
+      it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab;
       off_p += cd.n;
       for (int s = 0; s < 4; s++) off_tab += 2LL * vn[s];
       items.push_back(it);
@@ -250,7 +252,25 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   for (int s = 0; s < 4; s++) tot_tab += 2LL * last.p.vn[s];
   HIPCHK(c, c->d_items.ensure(count));
   HIPCHK(c, c->d_p.ensure((size_t)tot_p + 512));
+  HIPCHK(c, c->d_q.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_err.ensure((size_t)tot_p + 512));
+  // The OLS stage of a work-item depends only on the PCM and on the OLS part of its parameters.
+  // DDS candidates of one frame mostly differ in a few coefficients, so many items of a launch have
+  // identical OLS stages: run each distinct one once (the "leader") and let the others' cascade
+  // read the leader's p_lpc stream.  ols_lead[i] = index of the item whose OLS result item i uses.
+  std::vector<int> ols_lead(count);
+  {
+    typedef std::tuple<int, int, int, int, int, int, int, int, int, int, double, double, double, double, double> Key;
+    std::map<Key, int> seen;
+    for (int i = 0; i < count; i++) {
+      const WorkItem &it = items[i];
+      const ChanParam &q = it.p;
+      const Key k(it.frame, it.ch_self, it.ch_other, it.start, it.n, q.k, q.n_ols, q.a, q.b, q.du, q.lambda, q.nu_eff, q.beta_sum, q.beta_pow, q.beta_add);
+      auto ins = seen.emplace(k, i);
+      ols_lead[i] = ins.first->second;
+      items[i].off_pin = items[ols_lead[i]].off_p;
+    }
+  }
   if (want_pred) HIPCHK(c, c->d_pred.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
@@ -260,7 +280,10 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // waits for the OLS classes of its own group, so cascade work starts under the OLS tail.
   constexpr int kFastOls = 3;                       // OLS classes [0, kFastOls) form group 0
   std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][2];
-  for (int i = 0; i < count; i++) { idx_ols[items[i].ols_class].push_back(i); idx_lms[items[i].lms_class][items[i].ols_class >= kFastOls].push_back(i); }
+  for (int i = 0; i < count; i++) {
+    if (ols_lead[i] == i) idx_ols[items[i].ols_class].push_back(i);
+    idx_lms[items[i].lms_class][items[ols_lead[i]].ols_class >= kFastOls].push_back(i);
+  }
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
   std::vector<int> flat;
@@ -332,7 +355,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
     double isteps = 0; for (int i = 0; i < ll.count; i++) isteps += items[flat[ll.first + i]].n;
     Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps);
-    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p);
+    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p, c->d_q.p);
   }
   for (int si = kNumOlsClasses; si < kMark; si++)
     if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], c->cls_stream[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
@@ -342,7 +365,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   c->spans.push_back(sp_ols); c->spans.push_back(sp_lms);
   c->fam_launches[FAM_OLS]++; c->fam_launches[FAM_LMS]++;
   { Span sp(c, FAM_BIAS);
-    launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
+    launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -417,7 +440,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
-  c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_cost.release();
+  c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_cost.release();
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();
@@ -645,7 +668,7 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
   const int count = (int)items.size();
   long long tot_tab = 0;
   for (auto &it : items) for (int s = 0; s < 4; s++) tot_tab += 2LL * it.p.vn[s];
-  HIPCHK(c, c->d_items.ensure(count)); HIPCHK(c, c->d_p.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_err.ensure((size_t)n * count + 512));
+  HIPCHK(c, c->d_items.ensure(count)); HIPCHK(c, c->d_p.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_q.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_err.ensure((size_t)n * count + 512));
   HIPCHK(c, c->d_pred.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16)); HIPCHK(c, c->d_idx.ensure(count + 16));
   HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
   launch_tables(c->stream, c->d_items.p, count, c->d_tab.p);
@@ -657,11 +680,11 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
     if (plpc) HIPCHK(c, hipMemcpy(plpc + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
     { Span sp(c, FAM_LMS);
       LmsRingCap rc; for (int q = 0; q < 4; q++) rc.c[q] = items[i].p.vn[q] + 1;
-      launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, rc, view(c), c->d_tab.p, c->d_p.p); }
+      launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, rc, view(c), c->d_tab.p, c->d_p.p, c->d_q.p); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_q.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
   }
-  { Span sp(c, FAM_BIAS); launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_p.p, c->d_err.p, c->d_pred.p); }
+  { Span sp(c, FAM_BIAS); launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, c->d_pred.p); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   collect_spans(c);
   HIPCHK(c, hipGetLastError());

@@ -26,7 +26,7 @@ struct LmsRingCap { int c[4]; };   // per-stage history ring capacity (doubles) 
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc);
 int lms_max_wg_per_cu(int lms_class);          // register-file bound on resident workgroups per CU
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
-                const double *d_tab, double *d_p);
+                const double *d_tab, const double *d_p /*p_lpc in*/, double *d_q /*p_lpc+p_lms out*/);
 void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
                  const double *d_p, int *d_err, int *d_pred /*nullable*/);
 // ---- costs / s2u (kernels_misc.hip)

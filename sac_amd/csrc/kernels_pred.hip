@@ -93,7 +93,7 @@ template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MI
 template <> struct LmsCfg<2> { using C = LmsB; static constexpr int NL = 512, MINB = 1; };
 
 template <int CLS>
-__global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, double *pbuf, LmsRingCap rc) {
+__global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NL = LmsCfg<CLS>::NL;
   using C = typename LmsCfg<CLS>::C;
@@ -103,17 +103,17 @@ __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(cons
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  lms_stage<ExecDev<NL>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_p, smem, rc.c, v.prof);
+  lms_stage<ExecDev<NL>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof);
 }
 
 template <int CLS>
-static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, LmsRingCap rc, PcmView v, const double *d_tab, double *d_p) {
+static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, LmsRingCap rc, PcmView v, const double *d_tab, const double *d_p, double *d_q) {
   constexpr int NL = LmsCfg<CLS>::NL;
   using C = typename LmsCfg<CLS>::C;
   static bool once = false;
   if (!once) { (void)hipFuncSetAttribute((const void *)k_lms<CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LmsLds<NL, C>::bytes()); once = true; }
   const size_t bytes = LmsLds<NL, C>::bytes(rc.c);
-  hipLaunchKernelGGL((k_lms<CLS>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_tab, d_p, rc);
+  hipLaunchKernelGGL((k_lms<CLS>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_tab, d_p, d_q, rc);
 }
 
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
@@ -124,11 +124,11 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
 int lms_max_wg_per_cu(int lms_class) { return lms_class == 2 ? 1 : 2; }
 
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
-                const double *d_tab, double *d_p) {
+                const double *d_tab, const double *d_p, double *d_q) {
   if (count <= 0) return;
-  if (lms_class == 0) launch_lms_c<0>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
-  else if (lms_class == 1) launch_lms_c<1>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
-  else launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p);
+  if (lms_class == 0) launch_lms_c<0>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q);
+  else if (lms_class == 1) launch_lms_c<1>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q);
+  else launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q);
 }
 
 // ------------------------------------------------------------------ stage 3: bias + residual

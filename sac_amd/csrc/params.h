@@ -46,7 +46,8 @@ struct WorkItem {
   int start, n;       // window [start, start+n) inside the frame
   int lms_class;      // 0/1/2 register-capacity class of the cascade kernel
   int ols_class;      // index into kOlsClassMax (LDS capacity class of the OLS kernel)
-  long long off_p;    // doubles: p_lpc / p_lpc+p_lms stream [n]
+  long long off_p;    // doubles: this item's p_lpc stream in the OLS buffer and its p_lpc+p_lms stream in the cascade buffer [n]
+  long long off_pin;  // doubles: where the cascade reads p_lpc (== off_p unless the OLS result is shared with another item)
   long long off_err;  // int32 residual [n]
   long long off_tab;  // doubles: per stage {mutab[vn], powtab[vn]}, stages back to back
   double sum_powtab[kStages];   // filled by the table kernel

@@ -86,7 +86,7 @@ struct LmsLds {
 
 template <class E, class C>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
-                     const int *self, int n, double *pio, char *lds_base, const int *ringcap,
+                     const int *self, int n, const double *pin_g, double *pout_g, char *lds_base, const int *ringcap,
                      unsigned long long *prof = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
@@ -144,8 +144,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   for (int t0 = 0; t0 < n; t0 += kLmsChunk) {
     // ---- stage a chunk of p_lpc / target in, flush the previous chunk of p_lpc+p_lms out
     ex.par([&](int l) {
-      if (t0 > 0) pio[t0 - kLmsChunk + l] = L.pout[l];
-      if (t0 + l < n) { L.pin[l] = pio[t0 + l]; L.sv[l] = self[t0 + l]; }
+      if (t0 > 0) pout_g[t0 - kLmsChunk + l] = L.pout[l];
+      if (t0 + l < n) { L.pin[l] = pin_g[t0 + l]; L.sv[l] = self[t0 + l]; }
     });
     ex.sync();
     const int tend = (n - t0 < kLmsChunk) ? n - t0 : kLmsChunk;
@@ -341,7 +341,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // flush the last chunk
   ex.par([&](int l) {
     const int t0 = ((n - 1) / kLmsChunk) * kLmsChunk;
-    if (n > 0 && t0 + l < n) pio[t0 + l] = L.pout[l];
+    if (n > 0 && t0 + l < n) pout_g[t0 + l] = L.pout[l];
   });
 }
 

@@ -19,7 +19,7 @@ static void run_lms(const ChanParam &p, const double *sp, const double *tab, con
   std::vector<char> lds(LmsLds<NL, C>::bytes());
   ExecEmu<NL> ex;
   const int rc[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};   // tight rings, as the host sizes them
-  lms_stage<ExecEmu<NL>, C>(ex, p, sp, tab, self, n, pio, lds.data(), rc);
+  lms_stage<ExecEmu<NL>, C>(ex, p, sp, tab, self, n, pio, pio, lds.data(), rc);
 }
 
 // samples planar [nch][total] mean-removed; stats [nch][3] = {min,max,mean}
