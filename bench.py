@@ -216,6 +216,8 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_times(); class_times()
+    for ctx, _, _ in groups:
+        ctx.eval_stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -228,6 +230,8 @@ def main():
         dt = float(tmax.item())
     kt = kernel_times()
     ct = class_times()
+    ev = [ctx.eval_stats() for ctx, _, _ in groups]
+    ev_req, ev_memo = sum(e[0] for e in ev), sum(e[1] for e in ev)
 
     samples_per_step = args.frames * n * 2 * world
     value = samples_per_step * args.steps / dt / 1e6
@@ -264,6 +268,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": int(dlaunch), "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": dbytes / max(dlaunch, 1),
                          "note": "latency/fp64-VALU-bound recurrences; HBM fraction is expected to be << 1 % (SURVEY.md 8d)"},
+            # the search never computes an identical channel evaluation twice within one batch (memo cleared
+            # by every staging, i.e. every step): requested vs answered without recomputation, this rank
+            "search_channel_evaluations": {"requested": ev_req, "shared_or_memoised": ev_memo},
             "kernel_ms": {k: round(v["ms"], 2) for k, v in kt.items()},
             "kernel_launches": {k: v["launches"] for k, v in kt.items()},
             "kernel_instances_ms": {k: round(v[0], 2) for k, v in sorted(cands.items())},

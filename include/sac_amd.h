@@ -87,6 +87,14 @@ int sacamd_get_stats(sacamd_ctx *ctx, int32_t *out /* [nframes][nch][4] = mean,m
 int sacamd_evaluate(sacamd_ctx *ctx, const sacamd_cfg *cfg, int ncand, const int *cand_frame,
                     const float *coefs /* [ncand][58] */, double *costs /* [ncand] */);
 
+/* Within one staged batch sacamd_evaluate never computes the same channel evaluation twice: the cost of
+ * a channel's residual is a pure function of (frame, channels, window, that slot's predictor parameters),
+ * and DDS candidates share most of them with their parent and with each other.  Identical evaluations
+ * are looked up (memo cleared by every frames_upload / frames_attach / analyse, i.e. it never outlives
+ * the staged PCM) or computed once; results are bit-identical to evaluating every candidate in full.
+ * out2 = { channel evaluations requested, of those answered without recomputation } since the last reset. */
+int sacamd_eval_stats(sacamd_ctx *ctx, long long *out2, int reset);
+
 /* ---- (4) final prediction pass -------------------------------------------------------------
  * Replaces: PredictFrame(base_profile, error, 0, numsamples, false) + CnvError_S2U
  * (libsac.cpp:477-478, 429-441).  One profile per staged frame. */

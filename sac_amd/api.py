@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "sacamd_frames_attach_s16_device", "sacamd_analyse", "sacamd_get_stats", "sacamd_evaluate",
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
-    "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_debug_ols_profile", "sacamd_abi_version",
+    "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version",
 ]
 
 
@@ -281,6 +281,12 @@ class Context:
         out = np.zeros(16, np.uint64)
         self._chk(self.lib.sacamd_debug_ols_profile(self.h, int(on), _vp(out)))
         return out
+
+    def eval_stats(self, reset=True):
+        """(channel evaluations requested by the search, of those answered from the per-batch memo)."""
+        out = np.zeros(2, np.int64)
+        self._chk(self.lib.sacamd_eval_stats(self.h, _vp(out), int(reset)))
+        return int(out[0]), int(out[1])
 
     def class_times(self, reset=True):
         """per kernel instance: {(kind, class): (ms, launches, item_steps)}, kind 'ols' | 'lms'."""

@@ -128,6 +128,11 @@ struct sacamd_ctx {
   bool coder_tables = false;
   struct EncOut { std::vector<unsigned char> bytes; int mapped = 0, maxbpn = 0; };
   std::vector<EncOut> enc;   // [frame*nch+ch]
+  // per-channel search costs already computed for the staged batch: key = (frame, channels, window,
+  // every predictor parameter of the slot) as raw bytes -> cost of that channel's residual
+  std::map<std::string, double> eval_cache;
+  int eval_cache_kind = -1;
+  long long eval_hits = 0, eval_items = 0;
   // timing
   std::vector<TimedSpan> spans;
   std::vector<TraceSpan> trace;
@@ -452,6 +457,7 @@ API const char *sacamd_last_error(const sacamd_ctx *c) { return c ? c->err.c_str
 
 // ================================================================== (1) staging
 static int stage_common(sacamd_ctx *c, int nframes, int framesize, const int *numsamples) {
+  c->eval_cache.clear();
   if (!c || nframes < 1 || nframes > c->max_frames || !numsamples) return fail(c, SACAMD_ERR_ARG, "bad frame count");
   for (int f = 0; f < nframes; f++)
     if (numsamples[f] < 1 || numsamples[f] > c->max_framesize) return fail(c, SACAMD_ERR_ARG, "numsamples outside [1,max_framesize]");
@@ -509,6 +515,7 @@ API int sacamd_analyse(sacamd_ctx *c, const sacamd_cfg *cfg) {
   if (!c || !cfg) return SACAMD_ERR_ARG;
   if (c->nframes < 1 || !c->raw_kind) return fail(c, SACAMD_ERR_STATE, "no frames staged");
   HIPCHK(c, hipSetDevice(c->device));
+  c->eval_cache.clear();                       // frame statistics (clamp ranges, mean) are about to be recomputed
   unsigned char *used = nullptr;
   if (cfg->sparse_pcm) {
     const size_t ub = (size_t)c->nframes * c->nch * 65540;
@@ -576,19 +583,57 @@ API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const i
   std::vector<WorkItem> items;
   int r = build_items(c, cands, items);
   if (r) return r;
-  r = run_predict(c, items, false);
-  if (r) return r;
-  std::vector<long long> off(items.size());
-  std::vector<int> n(items.size());
-  for (size_t i = 0; i < items.size(); i++) { off[i] = items[i].off_err; n[i] = items[i].n; }
-  std::vector<double> cv;
-  if (cfg->optimize_cost == SACAMD_COST_BITPLANE) {
-    // CostBitplane (cost.h:144-176): S2U, maxbpn from the window, full coder, byte count
-    r = bitplane_costs(c, off, n, cv);
-  } else {
-    r = run_costs(c, cfg->optimize_cost, off, n, c->d_err.p, cv);
+  // A channel's residual -- hence its cost -- is a pure function of (frame, channels, window, the
+  // slot's predictor parameters).  Late DDS candidates mostly leave one channel's parameters as the
+  // parent has them, and the N candidates of a generation share most of theirs, so identical
+  // channel evaluations are looked up (across calls, for the staged batch) or computed once.
+  if (c->eval_cache_kind != cfg->optimize_cost) { c->eval_cache.clear(); c->eval_cache_kind = cfg->optimize_cost; }
+  auto key_of = [](const WorkItem &it) {
+    int head[6] = {it.frame, it.ch_self, it.ch_other, it.slot, it.start, it.n};
+    std::string k(reinterpret_cast<const char *>(head), sizeof(head));
+    k.append(reinterpret_cast<const char *>(&it.p), sizeof(ChanParam));       // items are zero-filled before they are set up
+    return k;
+  };
+  std::vector<double> cv(items.size(), 0.0);
+  std::vector<int> src(items.size(), -1);             // index into `todo` for items that must be computed
+  std::vector<WorkItem> todo;
+  std::vector<std::string> todo_key;
+  {
+    std::map<std::string, int> pending;
+    long long off_p = 0, off_tab = 0;
+    for (size_t i = 0; i < items.size(); i++) {
+      std::string k = key_of(items[i]);
+      auto hit = c->eval_cache.find(k);
+      if (hit != c->eval_cache.end()) { cv[i] = hit->second; c->eval_hits++; continue; }
+      auto ins = pending.emplace(k, (int)todo.size());
+      if (ins.second) {
+        WorkItem it = items[i];
+        it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab;
+        off_p += it.n;
+        for (int q = 0; q < 4; q++) off_tab += 2LL * it.p.vn[q];
+        todo.push_back(it); todo_key.push_back(std::move(k));
+      } else c->eval_hits++;
+      src[i] = ins.first->second;
+    }
+    c->eval_items += (long long)items.size();
   }
-  if (r) return r;
+  if (!todo.empty()) {
+    r = run_predict(c, todo, false);
+    if (r) return r;
+    std::vector<long long> off(todo.size());
+    std::vector<int> n(todo.size());
+    for (size_t i = 0; i < todo.size(); i++) { off[i] = todo[i].off_err; n[i] = todo[i].n; }
+    std::vector<double> tv;
+    if (cfg->optimize_cost == SACAMD_COST_BITPLANE) {
+      // CostBitplane (cost.h:144-176): S2U, maxbpn from the window, full coder, byte count
+      r = bitplane_costs(c, off, n, tv);
+    } else {
+      r = run_costs(c, cfg->optimize_cost, off, n, c->d_err.p, tv);
+    }
+    if (r) return r;
+    for (size_t i = 0; i < todo.size(); i++) c->eval_cache.emplace(todo_key[i], tv[i]);
+    for (size_t i = 0; i < items.size(); i++) if (src[i] >= 0) cv[i] = tv[src[i]];
+  }
   // GetCost: sum over file channels 0,1 (libsac.cpp:355-361)
   for (int i = 0; i < ncand; i++) {
     double per_ch[2] = {0, 0};
@@ -776,6 +821,13 @@ API int sacamd_plan_subframes(sacamd_ctx *c, const int32_t *pcm, long long ch_st
     state[b] = avg_cost > 1.35;
   }
   return sacamd_subframes_from_states(state.data(), blen.data(), nblocks, min_frame_length, out, cap, count);
+}
+
+API int sacamd_eval_stats(sacamd_ctx *c, long long *out2, int reset) {
+  if (!c || !out2) return SACAMD_ERR_ARG;
+  out2[0] = c->eval_items; out2[1] = c->eval_hits;
+  if (reset) { c->eval_items = 0; c->eval_hits = 0; }
+  return 0;
 }
 
 API int sacamd_class_times(sacamd_ctx *c, double *out, int reset) {

@@ -325,3 +325,37 @@ def test_sacenc_cli_matches_python_driver(api, tmp_path):
         want = tmp_path / f"py{i}.sac"
         C.write_sac(str(want), info, maxlen, recs)
         assert (outdir / f"in{i}.sac").read_bytes() == want.read_bytes()
+
+
+def test_search_memo_is_exact(api, orc):
+    """The per-batch memo of channel evaluations (and the sharing of identical OLS stages) never changes a
+    cost: a batch of candidates that share channels with each other == the same candidates evaluated one
+    at a time in fresh state, and a repeated call is answered entirely from the memo."""
+    P = orc.profile()
+    rng = np.random.default_rng(9)
+    raw = synth_pcm(3000, 2, 808, RATE)
+    ctx = api.Context(2, FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    cfg = api.make_cfg("high", num_threads=4, fraction=0.5)
+    ctx.analyse(cfg)
+    base = P[:, 2].copy()
+    cands = [base.copy()]
+    for i in range(7):                                   # perturb one or two coefficients at a time, like late DDS candidates
+        g = base.copy()
+        for j in rng.choice([0, 2, 12, 14, 24, 25, 28, 31, 43, 44], size=1 + (i % 2), replace=False):
+            g[j] = np.float32(P[j, 0] + rng.random() * (P[j, 1] - P[j, 0]))
+        cands.append(g)
+    cands.append(cands[3].copy())                        # an exact duplicate
+    ctx.eval_stats()
+    got = ctx.evaluate(cfg, np.zeros(len(cands), np.int32), np.stack(cands))
+    req, memo = ctx.eval_stats()
+    assert req == 2 * len(cands) and memo >= 2           # at least the duplicate's two channels were shared
+    again = ctx.evaluate(cfg, np.zeros(len(cands), np.int32), np.stack(cands))
+    req2, memo2 = ctx.eval_stats()
+    assert np.array_equal(got, again) and memo2 == req2
+    single = []
+    for g in cands:                                      # fresh state for every candidate: nothing to share
+        ctx.analyse(cfg)
+        single.append(ctx.evaluate(cfg, np.zeros(1, np.int32), g[None])[0])
+    assert np.array_equal(got, np.array(single))
+    ctx.close()
