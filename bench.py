@@ -12,6 +12,9 @@ entropy cost) with the search run as 8-candidate DDS generations and --opt-reset
 in HBM before the timed region starts.  Frames shard across ranks with no data-path collective
 (weak scaling: every GPU gets --frames frames); the only collective is the final record gather.
 
+Every step stages the PCM again (which clears the library's per-batch memo of channel evaluations), so
+each step performs every distinct evaluation of its own search; nothing is carried from step to step.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
