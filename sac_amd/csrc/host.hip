@@ -133,6 +133,16 @@ struct sacamd_ctx {
   std::map<std::string, double> eval_cache;
   int eval_cache_kind = -1;
   long long eval_hits = 0, eval_items = 0;
+  // p_lpc streams of recent OLS evaluations of the staged batch, kOlsKeep per (frame, channel): a later
+  // generation whose candidate keeps a slot's OLS parameters (typically the parent's) reads the stream
+  // instead of recomputing it.  Same lifetime as eval_cache.
+  static constexpr int kOlsKeep = 2;
+  struct OlsKept { std::string key; long long stamp = -1; };
+  std::vector<OlsKept> ols_kept;              // [(frame*nch + ch)*kOlsKeep + e]
+  DevBuf<double> d_olskeep;
+  int ols_keep_len = 0;                       // doubles per kept stream (the search window)
+  long long ols_stamp = 0, ols_kept_hits = 0;
+  bool ols_keep_on = false;                   // set by sacamd_evaluate around its run_predict call
   // timing
   std::vector<TimedSpan> spans;
   std::vector<TraceSpan> trace;
@@ -273,9 +283,43 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       const Key k(it.frame, it.ch_self, it.ch_other, it.start, it.n, q.k, q.n_ols, q.a, q.b, q.du, q.lambda, q.nu_eff, q.beta_sum, q.beta_pow, q.beta_add);
       auto ins = seen.emplace(k, i);
       ols_lead[i] = ins.first->second;
-      items[i].off_pin = items[ols_lead[i]].off_p;
     }
   }
+  // kept streams of earlier calls (search only: the kept length is the search window)
+  std::vector<char> ols_skip(count, 0);           // leader whose p_lpc is already available
+  if (c->ols_keep_on) {
+    const int wlen = items[0].n;
+    if (c->ols_kept.empty()) {
+      c->ols_keep_len = wlen;
+      c->ols_kept.assign((size_t)c->nframes * c->nch * sacamd_ctx::kOlsKeep, sacamd_ctx::OlsKept());
+      HIPCHK(c, c->d_olskeep.ensure((size_t)c->ols_kept.size() * wlen));
+    }
+    c->ols_stamp++;
+    for (int i = 0; i < count; i++) {
+      if (ols_lead[i] != i || items[i].n != c->ols_keep_len) continue;
+      const WorkItem &it = items[i];
+      const ChanParam &q = it.p;
+      const double kd[5] = {q.lambda, q.nu_eff, q.beta_sum, q.beta_pow, q.beta_add};
+      const int ki[8] = {it.ch_other, it.start, it.n, q.k, q.n_ols, q.a, q.b, q.du};
+      std::string key(reinterpret_cast<const char *>(ki), sizeof(ki));
+      key.append(reinterpret_cast<const char *>(kd), sizeof(kd));
+      sacamd_ctx::OlsKept *e = &c->ols_kept[((size_t)it.frame * c->nch + it.ch_self) * sacamd_ctx::kOlsKeep];
+      int slot = -1;
+      for (int u = 0; u < sacamd_ctx::kOlsKeep; u++) if (e[u].stamp >= 0 && e[u].key == key) slot = u;
+      if (slot >= 0) { ols_skip[i] = 1; c->ols_kept_hits++; }
+      else {                                          // keep this stream in the least recently used entry not in use by this call
+        long long best = c->ols_stamp;
+        for (int u = 0; u < sacamd_ctx::kOlsKeep; u++) if (e[u].stamp < best) { best = e[u].stamp; slot = u; }
+        if (slot >= 0) e[slot].key = key;
+      }
+      if (slot >= 0) {
+        e[slot].stamp = c->ols_stamp;
+        const long long idx = (long long)(e - c->ols_kept.data()) + slot;
+        items[i].off_pin = (c->d_olskeep.p + idx * c->ols_keep_len) - c->d_p.p;     // offset relative to the p_lpc buffer
+      }
+    }
+  }
+  for (int i = 0; i < count; i++) if (ols_lead[i] != i) items[i].off_pin = items[ols_lead[i]].off_pin;
   if (want_pred) HIPCHK(c, c->d_pred.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
@@ -286,7 +330,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   constexpr int kFastOls = 3;                       // OLS classes [0, kFastOls) form group 0
   std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][2];
   for (int i = 0; i < count; i++) {
-    if (ols_lead[i] == i) idx_ols[items[i].ols_class].push_back(i);
+    if (ols_lead[i] == i && !ols_skip[i]) idx_ols[items[i].ols_class].push_back(i);
     idx_lms[items[i].lms_class][items[ols_lead[i]].ols_class >= kFastOls].push_back(i);
   }
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
@@ -445,7 +489,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
-  c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_cost.release();
+  c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();
@@ -457,7 +501,7 @@ API const char *sacamd_last_error(const sacamd_ctx *c) { return c ? c->err.c_str
 
 // ================================================================== (1) staging
 static int stage_common(sacamd_ctx *c, int nframes, int framesize, const int *numsamples) {
-  c->eval_cache.clear();
+  c->eval_cache.clear(); c->ols_kept.clear(); c->ols_keep_len = 0;
   if (!c || nframes < 1 || nframes > c->max_frames || !numsamples) return fail(c, SACAMD_ERR_ARG, "bad frame count");
   for (int f = 0; f < nframes; f++)
     if (numsamples[f] < 1 || numsamples[f] > c->max_framesize) return fail(c, SACAMD_ERR_ARG, "numsamples outside [1,max_framesize]");
@@ -515,7 +559,7 @@ API int sacamd_analyse(sacamd_ctx *c, const sacamd_cfg *cfg) {
   if (!c || !cfg) return SACAMD_ERR_ARG;
   if (c->nframes < 1 || !c->raw_kind) return fail(c, SACAMD_ERR_STATE, "no frames staged");
   HIPCHK(c, hipSetDevice(c->device));
-  c->eval_cache.clear();                       // frame statistics (clamp ranges, mean) are about to be recomputed
+  c->eval_cache.clear(); c->ols_kept.clear(); c->ols_keep_len = 0;   // frame statistics (clamp ranges, mean) are about to be recomputed
   unsigned char *used = nullptr;
   if (cfg->sparse_pcm) {
     const size_t ub = (size_t)c->nframes * c->nch * 65540;
@@ -618,7 +662,9 @@ API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const i
     c->eval_items += (long long)items.size();
   }
   if (!todo.empty()) {
+    c->ols_keep_on = true;
     r = run_predict(c, todo, false);
+    c->ols_keep_on = false;
     if (r) return r;
     std::vector<long long> off(todo.size());
     std::vector<int> n(todo.size());

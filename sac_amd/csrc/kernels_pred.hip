@@ -51,9 +51,9 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
-  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
-  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_p, smem, v.prof);
+  if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_pin, smem, v.prof);
+  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_pin, smem, v.prof);
+  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_pin, smem, v.prof);   // off_pin: where this item's p_lpc lives
 }
 
 template <int NL, int NMAX>

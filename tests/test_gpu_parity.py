@@ -359,3 +359,41 @@ def test_search_memo_is_exact(api, orc):
         single.append(ctx.evaluate(cfg, np.zeros(1, np.int32), g[None])[0])
     assert np.array_equal(got, np.array(single))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_kept_ols_streams_are_exact(api, orc):
+    """p_lpc streams kept from earlier generations (two per frame and channel, least recently used
+    replaced) never change a cost: generations evaluated one after the other in one context == every
+    candidate evaluated alone in fresh state.  The sequence revisits OLS parameter sets after they have
+    been replaced, and keeps them while only cascade coefficients move."""
+    P = orc.profile()
+    rng = np.random.default_rng(21)
+    raw = [synth_pcm(2500, 2, 900 + f, RATE) for f in range(2)]
+    ctx = api.Context(2, FRAMESIZE, 2)
+    ctx.upload_i32(raw, FRAMESIZE)
+    cfg = api.make_cfg("high", num_threads=4, fraction=0.5)
+    ctx.analyse(cfg)
+    base = P[:, 2].copy()
+
+    def perturb(g, idxs):
+        g = g.copy()
+        for j in idxs:
+            g[j] = np.float32(P[j, 0] + rng.random() * (P[j, 1] - P[j, 0]))
+        return g
+
+    variants = [base] + [perturb(base, rng.choice(56, size=3, replace=False)) for _ in range(3)]   # distinct parameter sets
+    gens = []
+    for rnd in range(8):                                 # walk over the variants so that kept entries get replaced and revisited
+        parent = variants[(rnd * 3) % len(variants)]
+        gens.append([parent] + [perturb(parent, rng.choice(56, size=1)) for _ in range(3)])
+    got = []
+    for g in gens:
+        fr = np.array([i % 2 for i in range(len(g))], np.int32)
+        got.append(ctx.evaluate(cfg, fr, np.stack(g)))
+    for g, have in zip(gens, got):
+        for i, cand in enumerate(g):
+            ctx.analyse(cfg)                             # fresh state: no memo, nothing kept
+            want = ctx.evaluate(cfg, np.array([i % 2], np.int32), cand[None])[0]
+            assert want == have[i]
+    ctx.close()
