@@ -24,6 +24,7 @@ constexpr int kLaplaceAvg = 1 << 17;      // avg_sum domain of the host table
 constexpr int kLaplacePlanes = 18;
 constexpr int kCoderChunk = 64;
 constexpr int kCoderHalo = 32;
+constexpr int kCoderStage = 512;          // range coder output bytes staged in LDS between two flushes
 
 struct CntL { unsigned short p1, cnt; };     // LinearCounterLimit as one 32-bit word
 
@@ -44,6 +45,12 @@ struct CoderTabs {
 struct CoderWin {            // staged data window of one chunk (with halo)
   int val[kCoderChunk + 2 * kCoderHalo];
   unsigned char msb[kCoderChunk + 2 * kCoderHalo];
+  // range coder output of the serial section, copied to the stream by all lanes afterwards
+  unsigned char stage[kCoderStage];
+  int fl[2];                  // bytes staged, their offset in the output stream
+  // wave-parallel decision (coder_step_wave): lanes that own no adaptive element load / store here
+  unsigned sinkc[64];
+  int sinkw[64];
 };
 
 // per-sample descriptor, packed into four ints held by the lane that computed it
@@ -55,12 +62,22 @@ struct CoderDescR {
 };
 
 struct RangeEnc {            // RangeCoderSH, encode side
+  // Output bytes go to an LDS staging buffer, not to memory: in the serial chain every global store
+  // would sit in the same in-order vmcnt queue as the prefetched context word, and waiting for that
+  // word would wait for the store acknowledgements of the decision before it.
   unsigned range, FFNum, Cache;
   unsigned long long lowc;
-  unsigned char *out;
-  int pos, cap;
-  SA_HD void init(unsigned char *o, int capacity) { range = 0xFFFFFFFFu; FFNum = 0; Cache = 0; lowc = 0; out = o; pos = 0; cap = capacity; }
-  SA_HD void put(unsigned b) { if (pos < cap) out[pos] = (unsigned char)b; pos++; }
+  unsigned char *out, *stage;
+  int pos, cap, spos;
+  SA_HD void init(unsigned char *o, int capacity, unsigned char *stage_buf) {
+    range = 0xFFFFFFFFu; FFNum = 0; Cache = 0; lowc = 0; out = o; pos = 0; cap = capacity; stage = stage_buf; spos = 0;
+  }
+  SA_HD void flush_serial() {                  // staging buffer full (long carry runs, the map header)
+#pragma nounroll
+    for (int i = 0; i < spos; i++) if (pos + i < cap) out[pos + i] = stage[i];
+    pos += spos; spos = 0;
+  }
+  SA_HD void put(unsigned b) { stage[spos++] = (unsigned char)b; if (spos == kCoderStage) flush_serial(); }
   SA_HD void shift_low() {
     const unsigned Carry = (unsigned)(lowc >> 32), low = (unsigned)lowc;
     if (low < 0xFF000000u || Carry) {
@@ -78,8 +95,10 @@ struct RangeEnc {            // RangeCoderSH, encode side
   SA_HD void stop() { for (int i = 0; i < 5; i++) shift_low(); }
 };
 
-SA_HD int idiv_s(int val, int s) { return val < 0 ? -(((-val) + (1 << (s - 1))) >> s) : (val + (1 << (s - 1))) >> s; }
-SA_HD int idiv_s64(long long val, int s) { return (int)(val < 0 ? -(((-val) + (1LL << (s - 1))) >> s) : (val + (1LL << (s - 1))) >> s); }
+// round-half-away-from-zero shifts (val < 0 ? -((-val + h) >> s) : (val + h) >> s), written without a
+// branch: the lanes of a wave-parallel decision differ in sign
+SA_HD int idiv_s(int val, int s) { const int m = val >> 31; const int r = (((val ^ m) - m) + (1 << (s - 1))) >> s; return (r ^ m) - m; }
+SA_HD int idiv_s64(long long val, int s) { const long long m = val >> 63; const long long r = (((val ^ m) - m) + (1LL << (s - 1))) >> s; return (int)((r ^ m) - m); }
 SA_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 SA_HD int ilog2i(int v) { int nb = 0; while (v >>= 1) nb++; return nb; }
 
@@ -131,7 +150,11 @@ template <int N> SA_HD int sse_interp(int pl, int ph, int pmod) {
   return clampi((pl * (xscale - pmod) + ph * pmod) / xscale, 1, kPScaleM);
 }
 
-SA_HD int fwd_at(const CoderTabs &T, int p) { return p <= kPScale / 2 ? (int)T.fwdh[p] : -(int)T.fwdh[kPScale - p]; }
+SA_HD int fwd_at(const CoderTabs &T, int p) {      // one load, no branch (lanes of a wave-parallel decision differ in p)
+  const bool lo = p <= kPScale / 2;
+  const int v = T.fwdh[lo ? p : kPScale - p];
+  return lo ? v : -v;
+}
 
 SA_HD void coder_tabs_init(CoderTabs &T, const short *g_fwd, const unsigned short *g_inv, int lane, int nl) {
   for (int i = lane; i <= kPScale / 2; i += nl) T.fwdh[i] = g_fwd[i];
@@ -292,6 +315,106 @@ SA_HD void coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, 
   M.ssemix[0] = sw[0]; M.ssemix[1] = sw[1];
 }
 
+#if defined(__HIPCC__)
+// ---- the same decision spread over the lanes of the wave (device only).  A lone lane issues one
+// instruction every four cycles or more whatever it computes, so the cost of a decision is its
+// instruction count: here every adaptive element is owned by a lane -- lane q holds mixer input q
+// and its weight (ref: pest, p_laplace, cref0..2 on lanes 0..4, cref3 on lane 5; sig: p_laplace,
+// csig0, csig1 on lanes 0..2), even / odd lanes hold the two SSE bins -- the dot product and the two
+// interpolations are DPP sums, and everything else is computed redundantly by all lanes.  Integer
+// arithmetic throughout, so the regrouping is exact; loads precede stores exactly as in coder_step.
+// `cur`: the prefetched csig0 word (all lanes); *upd: its update (uniform).  Only lane 0's rc is live.
+template <int LANE> __device__ __forceinline__ int coder_wlane(int sval, int old) {   // old with lane LANE replaced by the uniform sval
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "i"(LANE));
+  return old;
+}
+template <int CTRL> __device__ __forceinline__ int coder_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ void coder_step_wave(CoderModel &M, const CoderTabs &T, CoderWin &W, CoderDescR D, int bpn, unsigned cur,
+                                                unsigned *upd, RangeEnc &rc, int L) {
+  const int i1 = (D.a >> 16) & 0xffff, i2 = D.b & 0xffff, i3 = (D.b >> 16) & 0xffff;
+  const int i4 = D.c & 0xffff, mixc = (D.c >> 16) & 0xff, s1 = (D.c >> 24) & 0xff, s2 = D.d & 0xff;
+  const int type = (D.d >> 8) & 1, bit = (D.d >> 9) & 1, st_pest = (short)(D.d >> 16);
+  // element addresses as byte offsets from M; uniform candidates are written into their owner's lane
+  char *const mb = reinterpret_cast<char *>(&M);
+  auto off = [&](const void *q) { return __builtin_amdgcn_readfirstlane((int)(reinterpret_cast<const char *>(q) - mb)); };
+  int oc = (int)(reinterpret_cast<char *>(&W.sinkc[L]) - mb);
+  int ow = (int)(reinterpret_cast<char *>(&W.sinkw[L]) - mb);
+  if (type) {
+    oc = coder_wlane<1>(off(&M.p_laplace[bpn]), oc);
+    oc = coder_wlane<2>(off(&M.cref0[i1]), oc);
+    oc = coder_wlane<3>(off(&M.cref1[i2]), oc);
+    oc = coder_wlane<4>(off(&M.cref2[i3]), oc);
+    oc = coder_wlane<5>(off(&M.cref3[i4]), oc);
+    const int wb = off(&M.lmixref[mixc][0]) + 4 * L;
+    ow = L < 5 ? wb : ow;
+  } else {
+    oc = coder_wlane<0>(off(&M.p_laplace[bpn]), oc);
+    oc = coder_wlane<2>(off(&M.csig1[i2]), oc);
+    const int wb = off(&M.lmixsig[mixc][0]) + 4 * L;
+    ow = L < 3 ? wb : ow;
+  }
+  unsigned *cp = reinterpret_cast<unsigned *>(mb + oc);
+  int *wq = reinterpret_cast<int *>(mb + ow);
+  // ---- loads
+  unsigned cw = *cp;
+  if (!type && L == 1) cw = cur;
+  int w = *wq;
+  const int lb1 = M.sse_lb[s1], lb2 = M.sse_lb[s2];
+  int sw[2] = {M.ssemix[0], M.ssemix[1]};
+  int st = fwd_at(T, (int)(cw & 0xffff));
+  if (type && L == 0) st = st_pest;
+  if (L >= (type ? 5 : 3)) st = 0;
+  // mixer: sum of the products as (high, low 16 bits) pairs, reduced over lanes 0..7 of the row
+  const int prod = w * st;
+  int sh = prod >> 16, sl = prod & 0xffff;
+  sh += coder_dpp0<0x111>(sh); sl += coder_dpp0<0x111>(sl);     // row_shr:1
+  sh += coder_dpp0<0x112>(sh); sl += coder_dpp0<0x112>(sl);     // row_shr:2
+  sh += coder_dpp0<0x114>(sh); sl += coder_dpp0<0x114>(sl);     // row_shr:4
+  const int Sh = __builtin_amdgcn_readlane(sh, 7), Sl = __builtin_amdgcn_readlane(sl, 7);
+  // idiv_s64(Sh * 65536 + Sl, 16)
+  const int H = Sh + (Sl >> 16), Lo = Sl & 0xffff;
+  const int x = H + ((H >= 0) ? (Lo >= 32768 ? 1 : 0) : (Lo > 32768 ? 1 : 0));
+  const unsigned pk = pinv_lookup(T.pinv, x);
+  const int p1 = (int)(pk & 0xffff), sp1 = (short)(pk >> 16);
+  constexpr int xs = (2 * 2662) / 14;
+  const int odd = L & 1;
+  int q1, r1, q2, r2;
+  sse_bin<15>(sp1, &q1, &r1);
+  unsigned short *m1 = &M.sse[s1][lb1][q1 + odd];
+  const int my1 = *m1;
+  int t1 = my1 * (odd ? r1 : xs - r1);
+  t1 += coder_dpp0<0xB1>(t1);                                   // quad_perm [1,0,3,2]
+  const int pr1 = clampi(t1 / xs, 1, kPScaleM);
+  sse_bin<15>(fwd_at(T, pr1), &q2, &r2);
+  unsigned short *m2 = &M.sse[s2][lb2][q2 + odd];
+  const int my2 = *m2;
+  int t2 = my2 * (odd ? r2 : xs - r2);
+  t2 += coder_dpp0<0xB1>(t2);
+  const int pr2 = clampi(t2 / xs, 1, kPScaleM);
+  int sf[2] = {fwd_at(T, (pr1 + pr2 + 1) >> 1), sp1};
+  const int p = (int)(pinv_lookup(T.pinv, mix_dot<2>(sw, sf)) & 0xffff);
+  // ---- updates: each owner stores its element, the others their sink word
+  CntL c; c.p1 = (unsigned short)(cw & 0xffff); c.cnt = (unsigned short)(cw >> 16);
+  const CntL cn = cntl_next(c, bit, (type || L == 0) ? 150 : 300, T.divt);   // p_laplace (lane 0 of a sig decision) keeps limit 150
+  const unsigned nw = (unsigned)cn.p1 | ((unsigned)cn.cnt << 16);
+  *cp = nw;
+  *upd = (unsigned)__builtin_amdgcn_readlane((int)nw, 1);
+  mix_next<1>(&w, &st, p1, bit, type ? 800 : 700);
+  *wq = w;
+  unsigned short *h1 = L < 2 ? m1 : reinterpret_cast<unsigned short *>(&W.sinkw[L]);
+  unsigned short *h2 = L < 2 ? m2 : reinterpret_cast<unsigned short *>(&W.sinkw[L]);
+  *h1 = cnt16_next(my1, bit, 250);
+  *h2 = cnt16_next(my2, bit, 250);
+  mix_next<2>(sw, sf, p, bit, 250);
+  if (L == 0) {
+    rc.encode((unsigned)p, bit);
+    M.sse_lb[s1] = (unsigned char)bit; M.sse_lb[s2] = (unsigned char)bit;
+    M.ssemix[0] = sw[0]; M.ssemix[1] = sw[1];
+  }
+  asm volatile("" ::: "memory");        // decisions stay in program order (elements change owners between decisions)
+}
+#endif
+
 // ---- MapEncoder (map.cpp:3-101): 2 x 32768 used-flags, serial
 struct MapModel {
   unsigned short cnt[24], cctx[256];
@@ -353,16 +476,23 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
     for (int i = l; i < 65536; i += E::nl) { csig0[i].p1 = kPScale >> 1; csig0[i].cnt = 0; }
   });
   ex.sync();
-  ex.par([&](int l) { coder_model_init(M, T, plap_init, l, E::nl); });
+  ex.par([&](int l) { coder_model_init(M, T, plap_init, l, E::nl); if (l == 0) { W.fl[0] = 0; W.fl[1] = 0; }
+    for (int q = l; q < 64; q += E::nl) { W.sinkc[q] = 0; W.sinkw[q] = 0; } });
   ex.sync();
   // The adaptive chain is strictly serial: lane 0 runs it (single-lane LDS traffic), the other
   // lanes take part in the parallel context computation and keep their sample's descriptor in
   // registers, from where lane 0 fetches it with v_readlane.
   RangeEnc rc;
-  rc.init(out, cap);
+  rc.init(out, cap, W.stage);
+  // hand the bytes staged so far to the next parallel section (lane 0 only)
+  auto publish = [&]() { W.fl[0] = rc.spos; W.fl[1] = rc.pos; rc.pos += rc.spos; rc.spos = 0; };
+  auto flush_par = [&](int l) {
+    const int cntb = W.fl[0], at = W.fl[1];
+    for (int q = l; q < cntb; q += E::nl) if (at + q < cap) out[at + q] = W.stage[q];
+  };
   if (used) {
     ex.par([&](int l) {
-      if (l == 0) { map_model_init(MM, T.pinv); map_encode(MM, used, used + 32769, T, rc); }
+      if (l == 0) { map_model_init(MM, T.pinv); map_encode(MM, used, used + 32769, T, rc); publish(); }
     });
     ex.sync();
   }
@@ -370,6 +500,7 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
   for (int bpn = maxbpn; bpn >= 0; bpn--) {
     for (int s0 = 0; s0 < n; s0 += kCoderChunk) {
       ex.par([&](int l) {
+        flush_par(l);
         for (int q = l; q < kCoderChunk + 2 * kCoderHalo; q += E::nl) {
           const int k = s0 - kCoderHalo + q;
           const int v = (k >= 0 && k < n) ? s2u[k] : 0;
@@ -385,34 +516,73 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
       });
       const int cnt = (n - s0 < kCoderChunk) ? n - s0 : kCoderChunk;
       // serial chain; the csig0 word of the NEXT significance decision is fetched one decision
-      // ahead (HBM/L2 latency) and forwarded from the register when both hit the same context
-      ex.lane0([&]() {
-        CoderDescR D{ex.lane_geti(da, 0), ex.lane_geti(db, 0), ex.lane_geti(dc, 0), ex.lane_geti(dd, 0)};
-        int idx = (D.a >> 16) & 0xffff;
-        CntL cur = csig0[((D.d >> 8) & 1) ? 0 : idx];
-        for (int i = 0; i < cnt; i++) {
-          CoderDescR Dn = D; CntL nxt = cur; int idxn = idx;
-          const bool has_next = i + 1 < cnt;
-          if (has_next) {
-            Dn = CoderDescR{ex.lane_geti(da, i + 1), ex.lane_geti(db, i + 1), ex.lane_geti(dc, i + 1), ex.lane_geti(dd, i + 1)};
-            idxn = (Dn.a >> 16) & 0xffff;
-            if (!((Dn.d >> 8) & 1)) nxt = csig0[idxn];
+      // ahead (HBM/L2 latency) and forwarded from the register when both hit the same context.
+      // The store of a decision's csig0 update is issued at the start of the following decision,
+      // right before that prefetch: both then have a whole decision to complete, and the prefetch,
+      // issued after the store, observes it.
+#if defined(__HIPCC__)
+      if constexpr (E::is_device) {
+        ex.par([&](int l) {
+          unsigned *cs = reinterpret_cast<unsigned *>(csig0);
+          // csig0 index of decision k (-1: a refinement decision), from the lane that described it
+          auto sig_index = [&](int k) { const int a = ex.lane_geti(da, k), d = ex.lane_geti(dd, k); return ((d >> 8) & 1) ? -1 : ((a >> 16) & 0xffff); };
+          int idx = sig_index(0);
+          unsigned cur = cs[idx < 0 ? 0 : idx];
+          asm volatile("" : "+v"(cur));            // no load is pending when the loop is entered
+          bool pend = false; int pidx = 0; unsigned pval = 0;
+          for (int i = 0; i < cnt; i++) {
+            if (pend) { if (l == 0) cs[pidx] = pval; pend = false; }
+            const CoderDescR D{ex.lane_geti(da, i), ex.lane_geti(db, i), ex.lane_geti(dc, i), ex.lane_geti(dd, i)};
+            unsigned nxt = cur; int idxn = -1;
+            if (i + 1 < cnt) { idxn = sig_index(i + 1); if (idxn >= 0) nxt = cs[idxn]; }
+            unsigned upd = cur;
+            coder_step_wave(M, T, W, D, bpn, cur, &upd, rc, l);
+            if (idx >= 0) {
+              pend = true; pidx = idx; pval = upd;
+              if (idxn == idx) nxt = upd;
+            }
+            asm volatile("" : "+v"(nxt));          // the prefetch completes here, not behind the next decision's store
+            cur = nxt; idx = idxn;
           }
-          const bool is_sig = !((D.d >> 8) & 1);
-          CntL upd = cur;
-          coder_step(M, T, D, bpn, cur, &upd, rc);
-          if (is_sig) {
-            csig0[idx] = upd;
-            if (has_next && !((Dn.d >> 8) & 1) && idxn == idx) nxt = upd;
+          if (l == 0) { if (pend) cs[pidx] = pval; publish(); }
+        });
+      } else
+#endif
+      {
+        ex.lane0([&]() {
+          CoderDescR D{ex.lane_geti(da, 0), ex.lane_geti(db, 0), ex.lane_geti(dc, 0), ex.lane_geti(dd, 0)};
+          int idx = (D.a >> 16) & 0xffff;
+          CntL cur = csig0[((D.d >> 8) & 1) ? 0 : idx];
+          bool pend = false; int pidx = 0; CntL pval = cur;
+          for (int i = 0; i < cnt; i++) {
+            if (pend) { csig0[pidx] = pval; pend = false; }
+            CoderDescR Dn = D; CntL nxt = cur; int idxn = idx;
+            const bool has_next = i + 1 < cnt;
+            if (has_next) {
+              Dn = CoderDescR{ex.lane_geti(da, i + 1), ex.lane_geti(db, i + 1), ex.lane_geti(dc, i + 1), ex.lane_geti(dd, i + 1)};
+              idxn = (Dn.a >> 16) & 0xffff;
+              if (!((Dn.d >> 8) & 1)) nxt = csig0[idxn];
+            }
+            const bool is_sig = !((D.d >> 8) & 1);
+            CntL upd = cur;
+            coder_step(M, T, D, bpn, cur, &upd, rc);
+            if (is_sig) {
+              pend = true; pidx = idx; pval = upd;
+              if (has_next && !((Dn.d >> 8) & 1) && idxn == idx) nxt = upd;
+            }
+            D = Dn; cur = nxt; idx = idxn;
           }
-          D = Dn; cur = nxt; idx = idxn;
-        }
-      });
+          if (pend) csig0[pidx] = pval;
+          publish();
+        });
+      }
       ex.sync();
     }
   }
+  ex.par([&](int l) { flush_par(l); });
+  ex.sync();
   int len = 0;
-  ex.lane0([&]() { rc.stop(); len = rc.pos; });
+  ex.lane0([&]() { rc.stop(); rc.flush_serial(); len = rc.pos; });
   return len;   // valid on lane 0
 }
 

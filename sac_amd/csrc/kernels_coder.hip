@@ -6,7 +6,7 @@
 namespace sacamd {
 
 // Several independent streams (one wave each) per workgroup share one copy of the read-only tables.
-constexpr int kCoderStreamsPerWg = 4;   // upper bound; ~116 KB of LDS: one workgroup per CU, one stream per SIMD
+constexpr int kCoderStreamsPerWg = 6;   // upper bound; ~153 KB of LDS: one workgroup per CU (1536 streams resident on 256 CUs)
 struct CoderLdsLayout {
   static constexpr size_t o_tabs = 0;
   static constexpr size_t o_stream = (o_tabs + sizeof(CoderTabs) + 15) / 16 * 16;
@@ -51,8 +51,12 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   static bool once = false;
   if (!once) { (void)hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::bytes(kCoderStreamsPerWg)); once = true; }
   // the fewest streams per CU that still keep every stream resident at once (256 CUs): one-stream
-  // workgroups (two per CU) up to 512 streams, three per workgroup up to 768, four beyond
-  const int spw = count <= 512 ? 1 : (count <= 768 ? 3 : kCoderStreamsPerWg);
+  // workgroups (two per CU) up to 512 streams, then one workgroup per CU with three to six streams
+  // (a serial stream issues an instruction every few cycles, so two of them share a SIMD well;
+  // a second round of workgroups would double the latency of the whole launch)
+  static_assert(CoderLdsLayout::bytes(kCoderStreamsPerWg) <= 160 * 1024, "coder workgroup exceeds the LDS of a CU");
+  int spw = 1;
+  if (count > 512) { spw = 3; while (spw < kCoderStreamsPerWg && count > 256 * spw) spw++; }
   const int wgs = (count + spw - 1) / spw;
   hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_s2u_map, d_used, d_laplace,
                      d_fwd, d_inv, d_state, state_stride, d_out, d_len);

@@ -257,6 +257,29 @@ def test_edge_frames_ragged_batch_vs_oracle(api, orc):
         assert np.array_equal(dec, f)
 
 
+def test_many_coder_streams_per_workgroup(api, orc):
+    """The coder packs three to six streams into one workgroup once a batch has more than 512 of them
+    (two per channel: plain and remapped).  Batches of 200, 300 and 370 short stereo frames (800, 1200,
+    1480 streams) give the records of the same frames encoded eight at a time, and the oracle's for a sample."""
+    nf = 370
+    frames = [synth_pcm(96 + (i % 5) * 17, 2, 3000 + i, RATE) for i in range(nf)]
+    cfg = api.make_cfg("normal")
+    small = []
+    ctx = api.Context(2, FRAMESIZE, 8)
+    for i in range(0, nf, 8):
+        ctx.upload_i32(frames[i:i + 8], FRAMESIZE)
+        small += ctx.encode_frames(cfg)[0]
+    ctx.close()
+    for count in (200, 300, nf):
+        ctx = api.Context(2, FRAMESIZE, count)
+        ctx.upload_i32(frames[:count], FRAMESIZE)
+        recs, _ = ctx.encode_frames(cfg)
+        ctx.close()
+        assert recs == small[:count], count
+    for i in range(0, nf, 37):
+        assert small[i] == orc.encode_frame(frames[i], frame_cfg("normal"), FRAMESIZE)["record"]
+
+
 def test_baseline_configs_3_and_4_small(api, orc):
     """BASELINE.json configs[3] (--best: bitplane cost, fraction 0.5, sigma 0.25) and configs[4]
     (--veryhigh on a mixed 8-bit mono + 16-bit stereo corpus) at sizes the oracle finishes in
