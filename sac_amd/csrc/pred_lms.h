@@ -31,6 +31,9 @@ struct LmsClass {
   SA_HD static constexpr int first(int s) { return s == 0 ? 0 : s == 1 ? C0 : s == 2 ? C0 + C1 : C0 + C1 + C2; }
 };
 constexpr int kRlsMax = 10;
+// taps per lane whose history loads are issued together in the sweep: four where the tap state leaves
+// registers to spare, two in the large classes (which already overflow the 256-VGPR budget)
+template <class C> constexpr int lms_group() { return C::total > 16 ? 2 : 4; }
 
 template <int N> struct DArr { double v[N]; };
 
@@ -62,7 +65,7 @@ struct LmsLds {
   // footprint follows the taps actually in use, not the register-capacity class
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
-    for (int s = 0; s < 4; s++) d += (size_t)ringcap[s];
+    for (int s = 0; s < 4; s++) d += (size_t)ringcap[s] + 1;      // + the mirror element ring[cap] == ring[0]
     d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + NL * sizeof(int) + 16;
   }
@@ -72,7 +75,7 @@ struct LmsLds {
   }
   SA_HD void carve(char *base, const int *ringcap) {
     double *d = reinterpret_cast<double *>(base);
-    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ringcap[s]; }
+    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ringcap[s] + 1; }
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 8;
     pin = d; d += NL; pout = d; d += NL;
@@ -118,7 +121,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         PT[l].v[f + j] = on ? tp[ns[s] + tap] : 0.0;
       }
       tp += 2 * ns[s];
-      for (int i = l; i < cap[s]; i += NL) L.ring[s][i] = 0.0;
+      for (int i = l; i <= cap[s]; i += NL) L.ring[s][i] = 0.0;
     }
     if (l < 8) { L.bc[l] = 0.0; L.pv[l] = 0.0; }
     sa_stage_tables(L.libm, l, NL);
@@ -158,17 +161,36 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const double wg = L.bc[s];
           double d = 0.0, sp = 0.0;
           const double *ring = L.ring[s];
-          for (int j = 0; j < C::slots(s); j++) {
-            const int tap = j * NL + l;
-            if (j * NL < ns[s] && tap < ns[s]) {
-              int in = pos[s] + tap; if (in >= cap[s]) in -= cap[s];
-              int io = in + 1; if (io >= cap[s]) io -= cap[s];
-              const double xo = ring[io], xn = ring[in];
-              double w = fma(MT[l].v[f + j], wg * xo, W[l].v[f + j]);
-              w = clampd(w, -10.0, 10.0);
-              W[l].v[f + j] = w;
-              d = fma(xn, w, d);
-              sp = fma(PT[l].v[f + j], xn * xn, sp);
+          // Slots are processed in groups of kLmsGroup with all ring loads of a group issued before its
+          // arithmetic (one LDS round trip per group, not per tap).  Within an active group a lane
+          // whose tap lies beyond the stage length reads the last tap's history instead: its mutab /
+          // powtab entries are zero and its weight stays +0, so fma(0, ., w), fma(x, 0, d) and
+          // fma(0, ., sp) leave w, d and sp exactly as they were.
+          const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
+          constexpr int kLmsGroup = lms_group<C>();
+#pragma unroll
+          for (int j0 = 0; j0 < C::slots(s); j0 += kLmsGroup) {
+            if (j0 * NL < ns[s]) {
+              double xo[kLmsGroup], xn[kLmsGroup];
+#pragma unroll
+              for (int g = 0; g < kLmsGroup; g++) {
+                if (j0 + g < C::slots(s)) {
+                  int tap = (j0 + g) * NL + l; tap = tap < last ? tap : last;
+                  int in = ps + tap; if (in >= cp) in -= cp;
+                  xn[g] = ring[in]; xo[g] = ring[in + 1];
+                }
+              }
+#pragma unroll
+              for (int g = 0; g < kLmsGroup; g++) {
+                if (j0 + g < C::slots(s) && (j0 + g) * NL < ns[s]) {     // (uniform) slots beyond the stage length
+                  const int j = j0 + g;
+                  double w = fma(MT[l].v[f + j], wg * xo[g], W[l].v[f + j]);
+                  w = clampd(w, -10.0, 10.0);
+                  W[l].v[f + j] = w;
+                  d = fma(xn[g], w, d);
+                  sp = fma(PT[l].v[f + j], xn[g] * xn[g], sp);
+                }
+              }
             }
           }
           acc[l].v[s] = d; acc[l].v[4 + s] = sp;
@@ -260,6 +282,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
           int np = ps - 1; if (np < 0) np += cs;
           rg[np] = bps;
+          if (np == 0) rg[cs] = bps;        // mirror: ring[in + 1] needs no wrap in the sweep
         }
       });
       SA_TICK(4);
