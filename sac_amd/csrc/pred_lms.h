@@ -55,6 +55,7 @@ struct LmsLds {
   double *bc;       // [8]: wgrad[4], unused
   double *pin, *pout;
   double *rx, *rw, *rph;     // RLS history / weights mirror / P*x
+  double *P;                 // RLS inverse covariance, row l at P + l * kRlsMax (owned by the lanes of wave 2)
   double *pv;                // stage predictions p[0..4]
   double *exwm;              // expert weights mirror [2][5]
   double *cst;               // vmu[4], sum_powtab[4]
@@ -66,7 +67,7 @@ struct LmsLds {
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
     for (int s = 0; s < 4; s++) d += (size_t)ringcap[s] + 1;      // + the mirror element ring[cap] == ring[0]
-    d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
+    d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + NL * sizeof(int) + 16;
   }
   SA_HD static size_t bytes() {
@@ -80,6 +81,7 @@ struct LmsLds {
     bc = d; d += 8;
     pin = d; d += NL; pout = d; d += NL;
     rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
+    P = d; d += kRlsMax * kRlsMax;
     pv = d; d += 8; exwm = d; d += 10; cst = d; d += 8; hs = d; d += 16;
     libm = d; d += kLibmLdsDoubles;
     sv = reinterpret_cast<int *>(d);
@@ -107,8 +109,14 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // ---- init: tables -> registers, zero rings / weights
   // wave-0 lane roles of the mixer chain: lanes 0..9 = expert e=l/5, input i=l%5 (LS_ADA weight +
   // squared-gradient EMA in registers); lanes 0..m-1 = row l of the RLS inverse covariance P.
-  typename E::template Reg<double> exw_r, exeg_r, rw_r, ph_r, xo_r, dots_r, spow_r, rcp_r, exz_r;
-  typename E::template Reg<DArr<kRlsMax>> Prow;
+  // Per-lane state of the mixer chain.  Every wave uses its own few of these on its own lanes only, so
+  // they share four registers (the tap state already fills the register file in the large classes);
+  // the RLS matrix P lives in LDS and is held in registers only while wave 2 works on it.
+  typename E::template Reg<double> mr0, mr1, mr2, mr3;
+  auto &dots_r = mr0; auto &spow_r = mr1;                                   // wave 0, lanes 16..19
+  auto &exw_r = mr0; auto &exeg_r = mr1;                                    // wave 1, lanes 0..9
+  auto &rw_r = mr0; auto &ph_r = mr1; auto &xo_r = mr2; auto &rcp_r = mr3;  // wave 2
+  auto &exz_r = mr0;                                                        // wave 3
   ex.par([&](int l) {
     const double *tp = tab;
     for (int s = 0; s < 4; s++) {
@@ -130,8 +138,9 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     if (l < 10) L.exwm[l] = 1.0 / 5;
     if (l < 16) L.hs[l] = (l == 12 || l == 13) ? 0.5 : 0.0;
     if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }
-    exw_r[l] = 1.0 / 5; exeg_r[l] = 0.0; rw_r[l] = 0.0; ph_r[l] = 0.0; xo_r[l] = 0.0; dots_r[l] = 0.0; spow_r[l] = 0.0; rcp_r[l] = 0.0; exz_r[l] = 0.0;
-    for (int j = 0; j < kRlsMax; j++) Prow[l].v[j] = (j == (l & 63)) ? 1.0 : 0.0;   // identity rows on the lanes of every wave (wave 2 owns P)
+    mr0[l] = (l >> 6) == 1 ? 1.0 / 5 : 0.0;   // wave 1: LS_ADA expert weights start at 1/5
+    mr1[l] = 0.0; mr2[l] = 0.0; mr3[l] = 0.0;
+    if (l < kRlsMax * kRlsMax) L.P[l] = (l / kRlsMax == l % kRlsMax) ? 1.0 : 0.0;
   });
   ex.sync();
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
@@ -217,16 +226,18 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         ex.wave_par(2, [&](int g) {   // P update of row l (rls.cpp:47-56) of the PREVIOUS step
           const int l = g & 63;
           if (l < m) {
+            double *prow = L.P + l * kRlsMax;
 #pragma unroll
             for (int j = 0; j < kRlsMax; j++)
-              if (j < m) Prow[g].v[j] = fma(-denom, ph_r[g] * L.rph[j], Prow[g].v[j]) * inv_alpha;
+              if (j < m) prow[j] = fma(-denom, ph_r[g] * L.rph[j], prow[j]) * inv_alpha;
           }
         });
       }
       ex.wave_par(2, [&](int g) {
         const int l = g & 63;
         if (l < m) {   // ph = P x, row l (rls.cpp:33): needs only P and the RLS history, both final by now
-          ph_r[g] = dot_canon_m(m, [&](int j) { return Prow[g].v[j]; }, [&](int j) { return L.rx[j]; });
+          const double *prow = L.P + l * kRlsMax;   // (this lane's own row: no synchronisation with the update above)
+          ph_r[g] = dot_canon_m(m, [&](int j) { return prow[j]; }, [&](int j) { return L.rx[j]; });
           L.rph[l] = ph_r[g];
         }
       });
