@@ -136,12 +136,12 @@ struct sacamd_ctx {
   // p_lpc streams of recent OLS evaluations of the staged batch, kOlsKeep per (frame, channel): a later
   // generation whose candidate keeps a slot's OLS parameters (typically the parent's) reads the stream
   // instead of recomputing it.  Same lifetime as eval_cache.
-  static constexpr int kOlsKeep = 2;
+  static constexpr int kOlsKeep = 4;
   struct OlsKept { std::string key; long long stamp = -1; };
   std::vector<OlsKept> ols_kept;              // [(frame*nch + ch)*kOlsKeep + e]
   DevBuf<double> d_olskeep;
   int ols_keep_len = 0;                       // doubles per kept stream (the search window)
-  long long ols_stamp = 0, ols_kept_hits = 0;
+  long long ols_stamp = 0, ols_kept_hits = 0, ols_leaders = 0;
   bool ols_keep_on = false;                   // set by sacamd_evaluate around its run_predict call
   // timing
   std::vector<TimedSpan> spans;
@@ -297,6 +297,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     c->ols_stamp++;
     for (int i = 0; i < count; i++) {
       if (ols_lead[i] != i || items[i].n != c->ols_keep_len) continue;
+      c->ols_leaders++;
       const WorkItem &it = items[i];
       const ChanParam &q = it.p;
       const double kd[5] = {q.lambda, q.nu_eff, q.beta_sum, q.beta_pow, q.beta_add};
@@ -481,6 +482,7 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
 }
 
 API void sacamd_ctx_destroy(sacamd_ctx *c) {
+  if (c && c->tracing) std::fprintf(stderr, "[sacamd trace] search OLS streams: %lld distinct, %lld read from kept streams\n", c->ols_leaders, c->ols_kept_hits);
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); (void)hipStreamDestroy(c->stream); }

@@ -216,12 +216,12 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       });
       ex.sync();
       SA_TICK(2);
-      // ---- B: mixer chain.  Wave 0 turns the stage sums into the prediction and the stage gains;
-      // after one barrier the three updates that only feed the NEXT prediction run side by side on
-      // waves 1..3 (each then goes straight on to its share of the next sweep):
+      // ---- B: mixer chain.  Wave 0 turns the stage sums into the prediction (head), then into the
+      // stage gains.  The three updates that only feed the NEXT prediction run beside the stage gains
+      // on waves 1..3, between barrier H (head published) and barrier 2:
       //   wave 1  LS_ADA expert weights            wave 2  RLS / ALC            wave 3  BlendExp softmax
       // The RLS P-matrix update is deferred until after the next sweep's barrier, where it hides
-      // under wave 0's work.
+      // under wave 0's head.
       if (have_prev) {
         ex.wave_par(2, [&](int g) {   // P update of row l (rls.cpp:47-56) of the PREVIOUS step
           const int l = g & 63;
@@ -282,23 +282,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         }
       });
       SA_TICK(3);
-      ex.wave_par(0, [&](int l) {
-        // lanes 16..19: NLMS_Stream::Update scalar part (ls.h:47-48) + history push of stage l-16
-        if (l >= 16 && l < 20) {
-          const int sl = l - 16;
-          const double bps = sl == 0 ? bp[0] : (sl == 1 ? bp[1] : (sl == 2 ? bp[2] : bp[3]));
-          const int ps = sl == 0 ? pos[0] : (sl == 1 ? pos[1] : (sl == 2 ? pos[2] : pos[3]));
-          const int cs = sl == 0 ? cap[0] : (sl == 1 ? cap[1] : (sl == 2 ? cap[2] : cap[3]));
-          double *rg = sl == 0 ? L.ring[0] : (sl == 1 ? L.ring[1] : (sl == 2 ? L.ring[2] : L.ring[3]));
-          L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
-          int np = ps - 1; if (np < 0) np += cs;
-          rg[np] = bps;
-          if (np == 0) rg[cs] = bps;        // mirror: ring[in + 1] needs no wrap in the sweep
-        }
-      });
-      SA_TICK(4);
+      // Barrier H: the head has published this step's prediction pieces.  Wave 0 goes on to the stage
+      // gains (all the next sweep needs from it); waves 1..3 run, beside it, the three updates that only
+      // feed the NEXT prediction, so that after barrier 2 all four waves start the next sweep together.
       ex.sync();
-      SA_TICK(5);
       // ---- wave 1: LS_ADA experts (ls.h:224-236), lanes 0..9: expert e = l/5 (0: L1 loss, 1: L2), input i = l%5
       ex.wave_par(1, [&](int g) {
         const int l = g & 63;
@@ -362,11 +349,26 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         const double inv = 1.0 / (w0 + w1);
         if (E::is_lane0w()) { L.hs[12] = w0 * inv; L.hs[13] = w1 * inv; }
       });
+      ex.wave_par(0, [&](int l) {
+        // lanes 16..19: NLMS_Stream::Update scalar part (ls.h:47-48) + history push of stage l-16
+        if (l >= 16 && l < 20) {
+          const int sl = l - 16;
+          const double bps = sl == 0 ? bp[0] : (sl == 1 ? bp[1] : (sl == 2 ? bp[2] : bp[3]));
+          const int ps = sl == 0 ? pos[0] : (sl == 1 ? pos[1] : (sl == 2 ? pos[2] : pos[3]));
+          const int cs = sl == 0 ? cap[0] : (sl == 1 ? cap[1] : (sl == 2 ? cap[2] : cap[3]));
+          double *rg = sl == 0 ? L.ring[0] : (sl == 1 ? L.ring[1] : (sl == 2 ? L.ring[2] : L.ring[3]));
+          L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
+          int np = ps - 1; if (np < 0) np += cs;
+          rg[np] = bps;
+          if (np == 0) rg[cs] = bps;        // mirror: ring[in + 1] needs no wrap in the sweep
+        }
+      });
+      SA_TICK(4);
+      ex.sync();
+      SA_TICK(5);
       have_prev = true;
       for (int s = 0; s < 4; s++) { pos[s] -= 1; if (pos[s] < 0) pos[s] += cap[s]; }
       SA_TICK(6);
-      // (no barrier here: the next sweep only needs what wave 0 published before the barrier above;
-      //  everything waves 1..3 just wrote is consumed after the next sweep's barrier)
       SA_TICK(7);
     }
   }

@@ -386,7 +386,7 @@ def test_search_memo_is_exact(api, orc):
 
 @pytest.mark.gpu
 def test_kept_ols_streams_are_exact(api, orc):
-    """p_lpc streams kept from earlier generations (two per frame and channel, least recently used
+    """p_lpc streams kept from earlier generations (four per frame and channel, least recently used
     replaced) never change a cost: generations evaluated one after the other in one context == every
     candidate evaluated alone in fresh state.  The sequence revisits OLS parameter sets after they have
     been replaced, and keeps them while only cascade coefficients move."""
