@@ -246,8 +246,7 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
       it.ols_class = 0;
       while (p.n_ols > kOlsClassMax[it.ols_class]) it.ols_class++;
       const int *vn = p.vn;
-      it.lms_class = (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) ? 0
-                   : (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) ? 1 : 2;
+      it.lms_class = lms_class_for(vn);
       it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab;
       off_p += cd.n;
       for (int s = 0; s < 4; s++) off_tab += 2LL * vn[s];

@@ -24,6 +24,7 @@ void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab);
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p);
 struct LmsRingCap { int c[4]; };   // per-stage history ring capacity (doubles) of one launch
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc);
+int lms_class_for(const int *vn);               // cascade layout class for stage lengths vn[4]
 int lms_max_wg_per_cu(int lms_class);          // register-file bound on resident workgroups per CU
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, const double *d_p /*p_lpc in*/, double *d_q /*p_lpc+p_lms out*/);

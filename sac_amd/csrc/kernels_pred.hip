@@ -85,12 +85,20 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
 // (8192,4096,2048,1024) on 512 lanes with the middle class's slot counts.  The two larger ones are
 // capped at 256 VGPRs (a few chain temporaries go to scratch): two 4-wave workgroups resp. one
 // 8-wave workgroup per CU.
+// Tap-slot layouts (slots of NL taps per stage).  0: the small class; 1: twice that; 2: the profile maximum
+// (8192, 4096, 2048, 1024) on 512 lanes, a whole CU per work-item.  3 and 4 hold the same 30 slots as class 1
+// split differently: the search often makes ONE late stage long (stage 1 up to 3072, stage 2 up to 1280,
+// stage 3 up to 768 taps) or stage 0 alone (up to 5120), which class 1's per-stage caps would send to class 2.
 using LmsA = LmsClass<8, 4, 2, 1>;
 using LmsB = LmsClass<16, 8, 4, 2>;
+using LmsD = LmsClass<10, 12, 5, 3>;
+using LmsE = LmsClass<20, 4, 5, 1>;
 template <int CLS> struct LmsCfg;
 template <> struct LmsCfg<0> { using C = LmsA; static constexpr int NL = 256, MINB = 1; };
 template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MINB = 2; };
 template <> struct LmsCfg<2> { using C = LmsB; static constexpr int NL = 512, MINB = 1; };
+template <> struct LmsCfg<3> { using C = LmsD; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<4> { using C = LmsE; static constexpr int NL = 256, MINB = 2; };
 
 template <int CLS>
 __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {
@@ -117,7 +125,23 @@ static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_id
 }
 
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
-  return lms_class == 0 ? LmsLds<256, LmsA>::bytes(rc.c) : lms_class == 1 ? LmsLds<256, LmsB>::bytes(rc.c) : LmsLds<512, LmsB>::bytes(rc.c);
+  switch (lms_class) {
+    case 0: return LmsLds<256, LmsA>::bytes(rc.c);
+    case 1: return LmsLds<256, LmsB>::bytes(rc.c);
+    case 3: return LmsLds<256, LmsD>::bytes(rc.c);
+    case 4: return LmsLds<256, LmsE>::bytes(rc.c);
+    default: return LmsLds<512, LmsB>::bytes(rc.c);
+  }
+}
+
+// first layout, in order of cost, whose per-stage slots hold the item's stage lengths
+int lms_class_for(const int *vn) {
+  auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
+  if (fits(256, LmsA::c0, LmsA::c1, LmsA::c2, LmsA::c3)) return 0;
+  if (fits(256, LmsB::c0, LmsB::c1, LmsB::c2, LmsB::c3)) return 1;
+  if (fits(256, LmsD::c0, LmsD::c1, LmsD::c2, LmsD::c3)) return 3;
+  if (fits(256, LmsE::c0, LmsE::c1, LmsE::c2, LmsE::c3)) return 4;
+  return 2;
 }
 
 // register-file bound on resident workgroups per CU (237 / 256 / 256 registers, 4 / 4 / 8 waves)
@@ -126,9 +150,13 @@ int lms_max_wg_per_cu(int lms_class) { return lms_class == 2 ? 1 : 2; }
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, const double *d_p, double *d_q) {
   if (count <= 0) return;
-  if (lms_class == 0) launch_lms_c<0>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q);
-  else if (lms_class == 1) launch_lms_c<1>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q);
-  else launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q);
+  switch (lms_class) {
+    case 0: launch_lms_c<0>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 1: launch_lms_c<1>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 3: launch_lms_c<3>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 4: launch_lms_c<4>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    default: launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+  }
 }
 
 // ------------------------------------------------------------------ stage 3: bias + residual

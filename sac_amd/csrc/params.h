@@ -17,7 +17,7 @@ constexpr int kStages = 4;
 // regressor-length capacity of each OLS kernel instance; the last one is the two-wave generic path
 constexpr int kNumOlsClasses = 8;
 constexpr int kOlsClassMax[kNumOlsClasses] = {16, 24, 32, 40, 48, 56, 64, 96};
-constexpr int kNumLmsClasses = 3;
+constexpr int kNumLmsClasses = 5;
 
 struct ChanParam {
   // OLS
@@ -44,7 +44,7 @@ struct WorkItem {
   int ch_other;       // file channel of the "other" regressor part (== ch_self for mono)
   int slot;           // predictor slot 0/1
   int start, n;       // window [start, start+n) inside the frame
-  int lms_class;      // 0/1/2 register-capacity class of the cascade kernel
+  int lms_class;      // register layout class of the cascade kernel (kernels_pred.hip, LmsCfg)
   int ols_class;      // index into kOlsClassMax (LDS capacity class of the OLS kernel)
   long long off_p;    // doubles: this item's p_lpc stream in the OLS buffer and its p_lpc+p_lms stream in the cascade buffer [n]
   long long off_pin;  // doubles: where the cascade reads p_lpc (== off_p unless the OLS result is shared with another item)

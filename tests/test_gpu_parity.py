@@ -152,7 +152,10 @@ def test_random_profiles_residuals(api, orc):
     profiles = [rand_profile(P, rng, cap=False, scale=1.0 + i) for i in range(4)]
     for taps, ols in (((8192, 4096, 2048, 1024), (32, 32, 32, 24, 8)),      # largest cascade class (512 lanes), OLS 64 / 64
                       ((4096, 2048, 1024, 512), (32, 9, 32, 12, 5)),        # middle cascade class, OLS 41 / 49 (panel kernels)
-                      ((300, 40, 8, 2), (32, 32, 32, 32, 32))):             # OLS 64 / 96 (two-wave generic path)
+                      ((300, 40, 8, 2), (32, 32, 32, 32, 32)),              # OLS 64 / 96 (two-row panel kernel)
+                      ((1200, 2600, 300, 700), (16, 8, 8, 8, 8)),           # cascade layout 3: long stages 1 and 3
+                      ((2100, 500, 1100, 600), (16, 8, 8, 8, 8)),           # cascade layout 3: long stages 2 and 3
+                      ((4700, 900, 1200, 200), (16, 8, 8, 8, 8))):          # cascade layout 4: stage 0 above 4096 with few other taps
         g = P[:, 2].copy()
         g[28], g[29], g[30], g[37] = taps; g[31], g[32], g[33], g[38] = taps
         g[24], g[9], g[25], g[26], g[27] = ols
