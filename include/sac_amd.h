@@ -151,7 +151,7 @@ int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
 /* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*8 + class)*3 + {0,1,2}] =
  * total ms (HIP events on the launch's stream), launches, item-steps processed; kind 0 = OLS capacity
  * classes (16,24,32 taps: k_ols<64,NMAX>; 40..96: k_ols<256,NMAX>), kind 1 = cascade
- * layout classes 0..4.  out has 48 entries. */
+ * layout classes 0..6.  out has 48 entries. */
 int sacamd_class_times(sacamd_ctx *ctx, double *out48, int reset);
 
 /* debug: on!=0 enables per-section cycle counters in the predictor kernels (slows them slightly);

@@ -93,12 +93,17 @@ using LmsA = LmsClass<8, 4, 2, 1>;
 using LmsB = LmsClass<16, 8, 4, 2>;
 using LmsD = LmsClass<10, 12, 5, 3>;
 using LmsE = LmsClass<20, 4, 5, 1>;
+// 5 and 6: the 15 slots of class 0 split for a long stage 1 / 2 or a long stage 0 (no scratch overflow)
+using LmsX = LmsClass<5, 5, 4, 1>;
+using LmsY = LmsClass<11, 1, 1, 2>;
 template <int CLS> struct LmsCfg;
 template <> struct LmsCfg<0> { using C = LmsA; static constexpr int NL = 256, MINB = 1; };
 template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MINB = 2; };
 template <> struct LmsCfg<2> { using C = LmsB; static constexpr int NL = 512, MINB = 1; };
 template <> struct LmsCfg<3> { using C = LmsD; static constexpr int NL = 256, MINB = 2; };
 template <> struct LmsCfg<4> { using C = LmsE; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<5> { using C = LmsX; static constexpr int NL = 256, MINB = 1; };
+template <> struct LmsCfg<6> { using C = LmsY; static constexpr int NL = 256, MINB = 1; };
 
 template <int CLS>
 __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {
@@ -130,6 +135,8 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 1: return LmsLds<256, LmsB>::bytes(rc.c);
     case 3: return LmsLds<256, LmsD>::bytes(rc.c);
     case 4: return LmsLds<256, LmsE>::bytes(rc.c);
+    case 5: return LmsLds<256, LmsX>::bytes(rc.c);
+    case 6: return LmsLds<256, LmsY>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
   }
 }
@@ -138,6 +145,8 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
 int lms_class_for(const int *vn) {
   auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
   if (fits(256, LmsA::c0, LmsA::c1, LmsA::c2, LmsA::c3)) return 0;
+  if (fits(256, LmsX::c0, LmsX::c1, LmsX::c2, LmsX::c3)) return 5;
+  if (fits(256, LmsY::c0, LmsY::c1, LmsY::c2, LmsY::c3)) return 6;
   if (fits(256, LmsB::c0, LmsB::c1, LmsB::c2, LmsB::c3)) return 1;
   if (fits(256, LmsD::c0, LmsD::c1, LmsD::c2, LmsD::c3)) return 3;
   if (fits(256, LmsE::c0, LmsE::c1, LmsE::c2, LmsE::c3)) return 4;
@@ -155,6 +164,8 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 1: launch_lms_c<1>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 3: launch_lms_c<3>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 4: launch_lms_c<4>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 5: launch_lms_c<5>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 6: launch_lms_c<6>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     default: launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
   }
 }
