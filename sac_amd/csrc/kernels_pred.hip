@@ -93,17 +93,19 @@ using LmsA = LmsClass<8, 4, 2, 1>;
 using LmsB = LmsClass<16, 8, 4, 2>;
 using LmsD = LmsClass<10, 12, 5, 3>;
 using LmsE = LmsClass<20, 4, 5, 1>;
-// 5 and 6: the 15 slots of class 0 split for a long stage 1 / 2 or a long stage 0 (no scratch overflow)
-using LmsX = LmsClass<5, 5, 4, 1>;
-using LmsY = LmsClass<11, 1, 1, 2>;
+// 5 and 6: 22 slots, the most that still fits 256 VGPRs without scratch overflow, split for a long stage 1
+// or a long stage 0: together they take about 60 % of the search's cascade work (need histogram of the
+// default bench run), leaving ~10 % to the 30-slot layouts
+using LmsX = LmsClass<6, 10, 4, 2>;
+using LmsY = LmsClass<13, 5, 3, 1>;
 template <int CLS> struct LmsCfg;
 template <> struct LmsCfg<0> { using C = LmsA; static constexpr int NL = 256, MINB = 1; };
 template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MINB = 2; };
 template <> struct LmsCfg<2> { using C = LmsB; static constexpr int NL = 512, MINB = 1; };
 template <> struct LmsCfg<3> { using C = LmsD; static constexpr int NL = 256, MINB = 2; };
 template <> struct LmsCfg<4> { using C = LmsE; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<5> { using C = LmsX; static constexpr int NL = 256, MINB = 1; };
-template <> struct LmsCfg<6> { using C = LmsY; static constexpr int NL = 256, MINB = 1; };
+template <> struct LmsCfg<5> { using C = LmsX; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<6> { using C = LmsY; static constexpr int NL = 256, MINB = 2; };
 
 template <int CLS>
 __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {

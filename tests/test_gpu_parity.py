@@ -156,8 +156,8 @@ def test_random_profiles_residuals(api, orc):
                       ((1200, 2600, 300, 700), (16, 8, 8, 8, 8)),           # cascade layout 3: long stages 1 and 3
                       ((2100, 500, 1100, 600), (16, 8, 8, 8, 8)),           # cascade layout 3: long stages 2 and 3
                       ((4700, 900, 1200, 200), (16, 8, 8, 8, 8)),           # cascade layout 4: stage 0 above 4096 with few other taps
-                      ((600, 1250, 1000, 100), (16, 8, 8, 8, 8)),           # cascade layout 5: 15 slots, long stages 1 and 2
-                      ((2700, 200, 100, 400), (16, 8, 8, 8, 8))):           # cascade layout 6: 15 slots, long stage 0
+                      ((600, 2500, 1000, 300), (16, 8, 8, 8, 8)),           # cascade layout 5: 22 slots, long stage 1
+                      ((3200, 1200, 700, 200), (16, 8, 8, 8, 8))):          # cascade layout 6: 22 slots, long stage 0
         g = P[:, 2].copy()
         g[28], g[29], g[30], g[37] = taps; g[31], g[32], g[33], g[38] = taps
         g[24], g[9], g[25], g[26], g[27] = ols
