@@ -134,10 +134,10 @@ def main():
     ap.add_argument("--verify", action="store_true", help="decode every record with the oracle afterwards (slow)")
     args = ap.parse_args()
     if args.frames <= 0:
-        # one step of F 20-s frames costs about 85 s of latency-bound final pass + coder plus ~0.36 s per frame
+        # one step of F 20-s frames costs about 60 s of latency-bound final pass + coder plus ~0.24 s per frame
         nrun = max(1, args.steps + args.warmup)
         per_step = 900.0 / nrun
-        args.frames = int(min(384, max(32, (per_step - 85.0 * args.seconds / 20.0) / (0.36 * args.seconds / 20.0))))
+        args.frames = int(min(384, max(32, (per_step - 60.0 * args.seconds / 20.0) / (0.24 * args.seconds / 20.0))))
 
     import torch
 
