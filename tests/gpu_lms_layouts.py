@@ -1,5 +1,8 @@
-"""Cascade throughput for chosen stage lengths (GPU box): distinct work-items of one layout class.
-usage: python tests/gpu_lms_layouts.py [lib.so] -- prints the lms kernel time for 1536 items x 4000 steps."""
+"""Cascade kernel time for chosen stage lengths (GPU box), to compare tap-slot layouts.
+usage: python tests/gpu_lms_layouts.py [lib.so]
+Each case evaluates 1536 candidates of which 40 are distinct (stage-3 length varied, same layout class); the
+rest are answered by the search memo, so the time printed is that of 40 concurrent work-items x 4000 steps,
+i.e. the per-step latency of the layout's kernel.  Pass another build of the library to compare."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,4 +26,4 @@ for taps in [(1200, 1200, 1000, 200), (500, 200, 1000, 200), (2300, 200, 200, 30
     ctx.evaluate(cfg, np.zeros(cnt, np.int32), G.astype(np.float32))
     kt = ctx.kernel_times(); ct = ctx.class_times()
     lms = {k[1]: round(v[0], 1) for k, v in ct.items() if k[0] == "lms"}
-    print(f"taps {taps}: lms tail {kt['lms']['ms']:7.1f} ms, ols {kt['ols']['ms']:7.1f} ms, lms instances (class: ms) {lms}  -> {cnt*steps/max(lms.values())/1e3:6.1f} M item-steps/s", flush=True)
+    print(f"taps {taps}: lms tail {kt['lms']['ms']:7.1f} ms, ols {kt['ols']['ms']:7.1f} ms, lms instances (class: ms) {lms}  -> {max(lms.values())*1e3/steps:5.2f} us per step", flush=True)
