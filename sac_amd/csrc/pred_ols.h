@@ -157,7 +157,10 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
   const double one_m_lambda = 1.0 - lambda;
 
   if (prof) tc = E::clock();
+  int sv_ahead = n > 0 ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
   for (int t = 0; t < n; t++) {
+    const int sv = sv_ahead;
+    if (t + 1 < n) sv_ahead = self[t + 1];
     ex.par([&](int l) {
       xr[l] = (double)xnext[l];
       if (l < no) L.X[l] = xr[l];
@@ -174,7 +177,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
     });
     ex.uni([&]() {
       pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
-      val = (double)self[t];
+      val = (double)sv;
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
@@ -386,7 +389,10 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
   const double one_m_lambda = 1.0 - lambda;
 
   if (prof) tc = E::clock();
+  int sv_ahead = n > 0 ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
   for (int t = 0; t < n; t++) {
+    const int sv = sv_ahead;
+    if (t + 1 < n) sv_ahead = self[t + 1];
     ex.par([&](int l) {
       if (l < 64) {
         xr[l] = (double)xnext[l];
@@ -404,7 +410,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
     });
     ex.leader([&]() {
       pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
-      val = (double)self[t];
+      val = (double)sv;
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
@@ -614,7 +620,10 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
   const double one_m_lambda = 1.0 - lambda;
 
   if (prof) tc = E::clock();
+  int sv_ahead = n > 0 ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
   for (int t = 0; t < n; t++) {
+    const int sv = sv_ahead;
+    if (t + 1 < n) sv_ahead = self[t + 1];
     ex.par([&](int l) {
       if (l < 64) {
 #pragma unroll
@@ -636,7 +645,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
     });
     ex.leader([&]() {
       pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
-      val = (double)self[t];
+      val = (double)sv;
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
