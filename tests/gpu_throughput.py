@@ -1,4 +1,6 @@
-"""Saturated throughput of the predictor stage kernels: identical work items, growing counts (GPU box)."""
+"""Saturated throughput of the predictor stage kernels: work items of one kernel class, growing counts (GPU box).
+The items differ slightly in their stage lengths (identical candidates would be answered by the search memo and
+share one OLS stream) and in the OLS regulariser, so every item runs both stages."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,7 +21,11 @@ for nA, nM0, taps in cases:
     if taps: g[28], g[29], g[30], g[37] = taps
     for cnt in counts:
         ctx.kernel_times()
-        ctx.evaluate(cfg, np.zeros(cnt, np.int32), np.tile(g, (cnt, 1)))
+        G = np.tile(g, (cnt, 1)); i = np.arange(cnt)
+        G[:, 37] += i % 64; G[:, 30] += (i // 64) % 64; G[:, 29] += i // 4096          # distinct cascade stages, same class
+        G[:, 0] = P[0, 0] + (P[0, 1] - P[0, 0]) * (0.25 + 0.5 * i / max(cnt - 1, 1))     # distinct OLS stage (coefficient 0)
+        ctx.analyse(cfg)                                                                 # forget memo and kept streams
+        ctx.evaluate(cfg, np.zeros(cnt, np.int32), G.astype(np.float32))
         kt = ctx.kernel_times()
         o, l, b = (kt[k]["ms"] for k in ("ols", "lms", "bias"))
         print(f"n_ols {nA+nM0:2d} taps {'dflt' if not taps else sum(taps)} items {cnt:5d}: ols {o:8.1f} ms ({o*1e3/steps:6.2f} us/step, {cnt*steps/o/1e3:7.1f} M item-steps/s)  "
