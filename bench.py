@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- SAC encode hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without torchrun: re-launches itself under it)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path (analyse -> DDS search -> final prediction -> bitplane/SSE
@@ -15,17 +15,29 @@ in HBM before the timed region starts.  Frames shard across ranks with no data-p
 Every step stages the PCM again (which clears the library's per-batch memo of channel evaluations), so
 each step performs every distinct evaluation of its own search; nothing is carried from step to step.
 
-Prints ONE JSON line on rank 0.
+Wall budget.  One step of the headline workload (384 frames x 20 s per GPU) takes minutes, so K steps
+may not fit the caller's time limit.  --budget-s (default 1200 s, counted from process start) bounds
+the run: warm-up steps run on a reduced batch (same kernels; there is nothing to warm but code-object
+load), then as many FULL steps as fit are timed, at least one, at most K.  The line reports `steps` =
+steps actually timed and `steps_requested` = K; `ms_per_step` x `steps` is the timed region.
+
+Output: rank 0 prints one cumulative JSON line after every timed step (the last line is the result;
+every line is a complete, self-consistent measurement of the steps finished so far) and, if the
+process is terminated early, the SIGTERM handler prints the latest one again.
 """
 import argparse
 import json
 import os
+import signal
+import sys
+import threading
+import time
+
+T_PROC_START = time.time()
 
 # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); every context here
-# uses 5 streams (main + one per kernel class) and several contexts may run concurrently.
+# uses 21 streams (main + one per kernel class) and several contexts may run concurrently.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-import sys
-import time
 
 import numpy as np
 
@@ -34,28 +46,56 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 RATE = 44100
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_GFLOPS = 78600.0   # MI355X public spec, vector fp64; the guide lists no fp64 row
 
 # algorithmic HBM bytes per predictor channel-step of each stage kernel (DESIGN.md "Data layout")
 STAGE_BYTES = {"ols": 4 + 4 + 8,     # own + other-channel PCM (int32), p_lpc out (fp64)
                "lms": 8 + 4 + 8,     # p_lpc in, PCM target, p_lpc+p_lms out
                "bias": 8 + 4 + 4}    # p in, PCM, residual out
+OLS_NMAX = (16, 24, 32, 40, 48, 56, 64, 96)
+
+
+def _synth_one(args):
+    from sac_amd.synth import synth_pcm
+    n, seed = args
+    return synth_pcm(n, 2, seed=seed, rate=RATE)
 
 
 def make_batch(nframes, seconds, seed0):
-    from sac_amd.synth import synth_pcm
-
+    """nframes synthetic stereo frames (distinct seeds) -> (planar int32 frames, interleaved int16 [nframes*n, 2], n).
+    Synthesis is host work outside the timed region; it is spread over the host cores."""
     n = int(seconds * RATE)
-    frames = [synth_pcm(n, 2, seed=seed0 + i, rate=RATE) for i in range(nframes)]
-    il = np.concatenate([f.T.astype(np.int16) for f in frames], axis=0)   # [nframes*n, 2] interleaved
-    return frames, np.ascontiguousarray(il), n
+    jobs = [(n, seed0 + i) for i in range(nframes)]
+    nproc = max(1, min(len(os.sched_getaffinity(0)), 32, nframes))
+    if nproc > 1 and nframes >= 8:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nproc) as pool:    # before torch / HIP are initialised in this process
+            frames = pool.map(_synth_one, jobs, chunksize=max(1, nframes // (4 * nproc)))
+    else:
+        frames = [_synth_one(j) for j in jobs]
+    il = np.empty((nframes * n, 2), np.int16)
+    for i, f in enumerate(frames):
+        il[i * n: (i + 1) * n] = f.T
+    return frames, il, n
 
 
-def shard_frames(total_frames, rank, world):
-    """Frames of a corpus are independent units (--opt-reset): contiguous block per rank."""
-    per = (total_frames + world - 1) // world
-    lo = min(rank * per, total_frames)
-    return list(range(lo, min(lo + per, total_frames)))
+def shard_frames(total_frames, rank, world, cost=None):
+    """Frames of a corpus are independent units (--opt-reset).  Without costs: contiguous blocks.  With a
+    per-frame cost estimate C*(E*T_opt + T): longest-first onto the least loaded rank."""
+    if cost is None:
+        per = (total_frames + world - 1) // world
+        lo = min(rank * per, total_frames)
+        return list(range(lo, min(lo + per, total_frames)))
+    order = sorted(range(total_frames), key=lambda f: (-cost[f], f))
+    load = [0.0] * world
+    mine = []
+    for f in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += cost[f]
+        if r == rank:
+            mine.append(f)
+    return sorted(mine)
 
 
 def gather_records(recs, rank, world, device):
@@ -70,8 +110,9 @@ def gather_records(recs, rank, world, device):
     dist.all_gather(metas, meta)                     # ranks may hold different numbers of frames
     max_n = int(max(int(m[0].item()) for m in metas))
     mx = int(max(int(m[1].item()) for m in metas))
-    lens = torch.zeros(max_n, dtype=torch.int64, device=device)
-    lens[: len(recs)] = torch.tensor([len(r) for r in recs], dtype=torch.int64)
+    lens = torch.zeros(max(max_n, 1), dtype=torch.int64, device=device)
+    if recs:
+        lens[: len(recs)] = torch.tensor([len(r) for r in recs], dtype=torch.int64)
     all_lens = [torch.zeros_like(lens) for _ in range(world)]
     dist.all_gather(all_lens, lens)
     tots = [m[1:2] for m in metas]
@@ -91,31 +132,36 @@ def gather_records(recs, rank, world, device):
     return res
 
 
-def cpu_baseline(seconds=3.0, nthreads=8, nframes=3):
-    """Reference `--high --opt-cfg=dds,N --opt-reset` CPU encode on a bounded sample: `nframes`
-    stereo frames of `seconds` s with max frame length == `seconds` s, so the search window is the
-    same 10 % of the frame and the evaluations-per-sample ratio equals the full-size workload's
-    (about 15 s of CPU work on one core)."""
+def cpu_baseline(frame, framesize, nthreads, mode="high"):
+    """Reference `--high --opt-cfg=dds,N --opt-reset` CPU encode of ONE frame of the benchmark's own batch
+    (frame 0 of rank 0, full length, same configuration) on one host core: genuine reference objects
+    (oracle/_ref) when they were built, else the oracle restatement."""
     from oracle_api import Checker, frame_cfg, ref_available
-    from sac_amd.synth import synth_pcm
 
     kind = "reference" if ref_available() else "port"
     chk = Checker("ref" if kind == "reference" else "orc")
-    n = int(seconds * RATE)
-    cfg = frame_cfg("high", num_threads=nthreads, reset=1)
-    dt, nbytes, nsamp = 0.0, 0, 0
-    for i in range(nframes):
-        raw = synth_pcm(n, 2, seed=4242 + i, rate=RATE)
-        t = time.time()
-        r = chk.encode_frame(raw, cfg, n)
-        dt += time.time() - t
-        nbytes += len(r["record"]); nsamp += raw.size
-    return {"value": nsamp / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": kind,
-            "seconds": dt, "bps": 8 * nbytes / nsamp,
-            "sample": f"{nframes} stereo frames of {seconds:g} s 44.1 kHz/16-bit, --high --opt-cfg=dds,{nthreads} --opt-reset, "
-                      f"max frame length {seconds:g} s (search window 10 % of the frame as in the 20 s workload); "
+    cfg = frame_cfg(mode, num_threads=nthreads, reset=1)
+    t = time.time()
+    r = chk.encode_frame(frame, cfg, framesize)
+    dt = time.time() - t
+    nsamp = frame.size
+    secs = frame.shape[1] / RATE
+    return {"value": nsamp / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": kind, "seconds": dt,
+            "bps": 8 * len(r["record"]) / nsamp,
+            "sample": f"frame 0 of this run's batch ({secs:g} s stereo 44.1 kHz/16-bit, {nsamp} samples), --{mode} "
+                      f"--opt-cfg=dds,{nthreads} --opt-reset; "
                       + ("genuine reference objects (oracle/_ref), candidates evaluated serially on 1 core"
-                         if kind == "reference" else "oracle restatement, 1 core")}
+                         if kind == "reference" else "oracle restatement, 1 core")}, r["record"]
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without torchrun: become `python -m torch.distributed.run ... bench.py ...`."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ["SAC_BENCH_T0"] = repr(T_PROC_START)
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -123,29 +169,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 0)),
-                    help="frames per GPU per step (0 = auto: 384, fewer when steps+warmup > 1 so that the run stays within ~15 min)")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("SAC_BENCH_BUDGET_S", 1200.0)),
+                    help="wall budget for the whole run, counted from process start; 0 = none (time exactly --steps)")
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 384)), help="frames per GPU per step")
     ap.add_argument("--seconds", type=float, default=float(os.environ.get("SAC_BENCH_SECONDS", 20.0)), help="frame length")
     ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SAC_BENCH_GROUPS", 1)),
-                    help="independent frame groups run concurrently on one GPU (own context + HIP streams each)")
+                    help="frame groups per GPU, each with its own context and HIP streams, software-pipelined: group g+1 "
+                         "starts its search when group g enters its latency-bound final pass + coder")
     ap.add_argument("--mode", default="high")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="decode every record with the oracle afterwards (slow)")
+    ap.add_argument("--verify", action="store_true", help="decode every record of the last step with the oracle afterwards (slow)")
     args = ap.parse_args()
-    if args.frames <= 0:
-        # one step of F 20-s frames costs about 60 s of latency-bound final pass + coder plus ~0.24 s per frame
-        nrun = max(1, args.steps + args.warmup)
-        per_step = 900.0 / nrun
-        args.frames = int(min(384, max(32, (per_step - 60.0 * args.seconds / 20.0) / (0.24 * args.seconds / 20.0))))
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
+    t_start = float(os.environ.get("SAC_BENCH_T0", T_PROC_START))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
+
+    # ---- host-side setup that must precede HIP initialisation (forks)
+    frames, il, n = make_batch(args.frames, args.seconds, seed0=1000 + 1000 * rank)
+    framesize = int(20 * RATE) if args.seconds >= 20 else n   # reference: max_framelen(20 s) * rate
 
     import torch
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -155,19 +206,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
 
     import sac_amd.api as api
-    from concurrent.futures import ThreadPoolExecutor
 
-    frames, il, n = make_batch(args.frames, args.seconds, seed0=1000 + 1000 * rank)
     d_pcm = torch.from_numpy(il).to(device)            # interleaved L/R int16, resident in HBM
     torch.cuda.synchronize()
-    framesize = int(20 * RATE) if args.seconds >= 20 else n   # reference: max_framelen(20 s) * rate
     cfg = api.make_cfg(args.mode, num_threads=args.dds_n, reset=1)
     # The kernels are latency-bound recurrences (one wave or one workgroup per frame x candidate x
-    # channel); independent groups of frames therefore run concurrently, each with its own context
-    # (own device buffers and HIP streams), so that one group's low-occupancy phases (final pass,
-    # range coder) overlap the others' search generations.
+    # channel).  A batch ends with a latency-bound tail (final pass: one work-item per frame x channel,
+    # then the range coder) that leaves most of the chip idle, so independent groups of frames, each with
+    # its own context (device buffers, HIP streams), are software-pipelined: while one group is in its
+    # tail the next group's search generations fill the chip.
     ngroups = max(1, min(args.groups, args.frames))
     bounds = [round(g * args.frames / ngroups) for g in range(ngroups + 1)]
     groups = []
@@ -175,34 +226,30 @@ def main():
         lo, hi = bounds[g], bounds[g + 1]
         ctx = api.Context(2, max(n, 16), hi - lo, device=local_rank)
         groups.append((ctx, np.arange(lo, hi, dtype=np.int64) * n, np.full(hi - lo, n, np.int32)))
-    pool = ThreadPoolExecutor(max_workers=ngroups)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_group(g):
+    def run_group(g, small=False):
         ctx, frame_off, nsamp = groups[g]
-        ctx.attach_s16_device(d_pcm.data_ptr(), frame_off, nsamp, framesize)
+        if small:     # warm-up: first frames of the group, 2 s each
+            k = min(len(nsamp), 8)
+            ns = np.minimum(nsamp[:k], 2 * RATE).astype(np.int32)
+            ctx.attach_s16_device(d_pcm.data_ptr(), frame_off[:k], ns, framesize)
+        else:
+            ctx.attach_s16_device(d_pcm.data_ptr(), frame_off, nsamp, framesize)
         ctx.analyse(cfg)
         recs, prof = ctx.encode_frames(cfg)      # ctypes releases the GIL: groups overlap on the GPU
         return recs
-
-    def step():
-        recs = [r for part in pool.map(run_group, range(ngroups)) for r in part]
-        if dist is not None:
-            allrecs = gather_records(recs, rank, world, device)
-        else:
-            allrecs = recs
-        return recs, allrecs
 
     def class_times():
         tot = {}
         for ctx, _, _ in groups:
             for k, v in ctx.class_times(reset=True).items():
-                a = tot.get(k, (0.0, 0.0, 0.0))
-                tot[k] = (a[0] + v[0], a[1] + v[1], a[2] + v[2])
+                a = tot.get(k, (0.0, 0.0, 0.0, 0.0))
+                tot[k] = tuple(x + y for x, y in zip(a, v))
         return tot
 
     def kernel_times():
@@ -216,78 +263,189 @@ def main():
                     tot[k]["ms"] += kt[k]["ms"]; tot[k]["launches"] += kt[k]["launches"]
         return tot
 
+    # ---- CPU baseline (rank 0, N=1): one frame of this very batch, before the timed region
+    cb, cb_record = None, None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cb, cb_record = cpu_baseline(frames[0], framesize, args.dds_n, args.mode)
+
+    # ---- warm-up on a reduced batch
     for _ in range(args.warmup):
-        step()
+        for g in range(ngroups):
+            run_group(g, small=True)
     kernel_times(); class_times()
     for ctx, _, _ in groups:
         ctx.eval_stats(reset=True)
+
+    # ---- timed region: pipelined groups, steps decided against the wall budget
+    budget = args.budget_s if args.budget_s > 0 else float("inf")
+    steps_max = max(1, args.steps)
+    lock = threading.Condition()
+    state = {"decided": 1, "final": None, "done": [[None] * ngroups for _ in range(steps_max)], "error": None}
+
+    def worker(g):
+        try:
+            step = 0
+            while True:
+                with lock:
+                    while state["final"] is None and state["decided"] <= step:
+                        lock.wait()
+                    if state["final"] is not None and step >= state["final"]:
+                        return
+                if g > 0 and step == 0:       # stagger: start when the previous group enters its final pass
+                    prev = groups[g - 1][0]
+                    while prev.progress()[0] < 2 and state["done"][0][g - 1] is None and state["error"] is None:
+                        time.sleep(0.02)
+                recs = run_group(g)
+                with lock:
+                    state["done"][step][g] = (recs, time.perf_counter())
+                    lock.notify_all()
+                step += 1
+        except BaseException as e:       # surface worker failures in the main thread
+            with lock:
+                state["error"] = e
+                lock.notify_all()
+
+    samples_per_step = args.frames * n * 2 * world
+    latest = {"line": None}
+
+    def on_term(signum, frame):
+        if rank == 0 and latest["line"] is not None:
+            sys.stdout.write(latest["line"] + "\n"); sys.stdout.flush()
+        os._exit(143)
+
+    signal.signal(signal.SIGTERM, on_term)
+
+    def build_line(nsteps, dt, allrecs, last_recs, final):
+        value = samples_per_step * nsteps / dt / 1e6
+        bps = 8 * sum(len(r) for r in allrecs) / samples_per_step
+        out = {
+            "metric": "encode MSamples/s + bps, 16-bit/44.1kHz stereo, --high; 1/2/4/8 MI355X",
+            "value": value, "unit": "MSamples/s", "n_gpus": world, "steps": nsteps, "steps_requested": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt * 1e3 / nsteps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.frames} frames/GPU x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
+                                   f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
+                       "frames_per_gpu": args.frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
+                       "pipelined_groups": ngroups, "rccl_ranks": world,
+                       "parallelism": f"frames sharded over {world} GPU(s), RCCL record gather",
+                       "warmup_batch": "min(8, frames of the group) frames x 2 s per group (code-object load only)",
+                       "budget_s": args.budget_s},
+            "bps": bps, "x_realtime": (args.frames * world * args.seconds * nsteps) / dt,
+            "complete": bool(final),
+        }
+        if cb is not None:
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            out["cpu_baseline"]["same_record_as_gpu"] = bool(last_recs and last_recs[0] == cb_record)
+        return out
+
+    def add_kernel_report(out, nsteps):
+        kt = kernel_times(); ct = class_times()
+        ev = [ctx.eval_stats() for ctx, _, _ in groups]
+
+        def kname(kind, cls):
+            if kind == "ols":
+                return f"k_ols<{64 if cls < 3 else 256},{OLS_NMAX[cls]}>"
+            return f"k_lms<{cls}>" + (" (canonical order, final pass)" if cls >= 7 else "")
+        cands = {}
+        for (kind, cls), (ms, launches, isteps, flops) in ct.items():
+            cands[kname(kind, cls)] = (ms, launches, STAGE_BYTES[kind] * isteps, isteps, flops)
+        cands["k_coder"] = (kt["coder"]["ms"], max(kt["coder"]["launches"], 1),
+                            (4 + out["bps"] / 8) * n * 2 * args.frames * nsteps, 0.0, 0.0)
+        dom = max(cands, key=lambda k: cands[k][0])
+        dms, dlaunch, dbytes, disteps, dflops = cands[dom]
+        avg_s = dms / 1e3 / max(dlaunch, 1)
+        achieved = dbytes / max(dlaunch, 1) / avg_s / 1e9 if avg_s > 0 else 0.0
+        # whole predictor: algorithmic fp64 flops of all OLS + cascade launches over the timed wall time
+        tot_flops = sum(v[4] for v in cands.values())
+        wall_s = out["ms_per_step"] * nsteps / 1e3
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "launches": int(dlaunch), "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": dbytes / max(dlaunch, 1),
+            "binds": "LDS instruction issue + dependent fp64 latency (neither HBM nor MFMA: ~1e4 flop/B, contractions <= 96 wide)",
+            "fp64": {"kernel_gflops": dflops / (dms / 1e3) / 1e9 if dms > 0 else 0.0,
+                     "job_gflops": tot_flops / wall_s / 1e9 if wall_s > 0 else 0.0,
+                     "peak_gflops": FP64_VALU_PEAK_GFLOPS,
+                     "kernel_frac": (dflops / (dms / 1e3) / 1e9 / FP64_VALU_PEAK_GFLOPS) if dms > 0 else 0.0,
+                     "job_frac": (tot_flops / wall_s / 1e9 / FP64_VALU_PEAK_GFLOPS) if wall_s > 0 else 0.0,
+                     "note": "kernel_*: the dominant kernel's algorithmic flops over ITS launch time (launches of other "
+                             "classes run concurrently on the same CUs); job_*: all predictor flops over the timed wall time"},
+            "kernel_item_steps_per_s": disteps / (dms / 1e3) if dms > 0 else 0.0,
+            "note": "latency/fp64-VALU-bound recurrences; HBM fraction is expected to be << 1 % (SURVEY.md 8d)"}
+        out["search_channel_evaluations"] = {"requested": sum(e[0] for e in ev), "shared_or_memoised": sum(e[1] for e in ev)}
+        out["kernel_ms"] = {k: round(v["ms"], 2) for k, v in kt.items()}
+        out["kernel_launches"] = {k: v["launches"] for k, v in kt.items()}
+        out["kernel_instances_ms"] = {k: round(v[0], 2) for k, v in sorted(cands.items())}
+        out["kernel_instances_launches"] = {k: int(v[1]) for k, v in sorted(cands.items())}
+        out["kernel_instances_algorithmic_MB"] = {k: round(v[2] / 1e6, 1) for k, v in sorted(cands.items())}
+        out["kernel_instances_gflops"] = {k: round(v[4] / (v[0] / 1e3) / 1e9, 1) for k, v in sorted(cands.items()) if v[0] > 0 and v[4] > 0}
+
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        recs, allrecs = step()
+    threads = [threading.Thread(target=worker, args=(g,), daemon=True) for g in range(ngroups)]
+    for t in threads:
+        t.start()
+    allrecs = last_recs = None
+    nsteps = 0
+    dt = 0.0
+    for step in range(steps_max):
+        # group 0 finishes step `step` first: decide whether another step fits the budget
+        with lock:
+            while state["done"][step][0] is None and state["error"] is None:
+                lock.wait()
+            if state["error"] is not None:
+                raise state["error"]
+        t_g0 = state["done"][step][0][1]
+        more = step + 1 < steps_max
+        if more:
+            per_step = (t_g0 - t0) / (step + 1)
+            tail = 0.6 * per_step if ngroups > 1 else 0.0          # the other groups still have to drain
+            est_end = (time.time() - t_start) + per_step * 1.08 + tail + 25.0
+            more = est_end < budget
+        if dist is not None:                 # all ranks take the same decision
+            flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            more = bool(flag.item())
+        with lock:
+            if more:
+                state["decided"] = step + 2
+            else:
+                state["final"] = step + 1
+            lock.notify_all()
+        with lock:
+            while any(d is None for d in state["done"][step]) and state["error"] is None:
+                lock.wait()
+            if state["error"] is not None:
+                raise state["error"]
+        recs = [r for part in state["done"][step] for r in part[0]]
+        state["done"][step] = [True] * ngroups      # drop the payloads
+        allrecs = gather_records(recs, rank, world, device) if dist is not None else recs
+        last_recs = recs
+        nsteps = step + 1
+        if not more:
+            break
+        if rank == 0:        # cumulative line (the timed region is still open: no barrier here)
+            dt_now = time.perf_counter() - t0
+            latest["line"] = json.dumps(build_line(nsteps, dt_now, allrecs, last_recs, final=False))
+            print(latest["line"], flush=True)
     barrier()
     dt = time.perf_counter() - t0
+    for t in threads:
+        t.join()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    kt = kernel_times()
-    ct = class_times()
-    ev = [ctx.eval_stats() for ctx, _, _ in groups]
-    ev_req, ev_memo = sum(e[0] for e in ev), sum(e[1] for e in ev)
 
-    samples_per_step = args.frames * n * 2 * world
-    value = samples_per_step * args.steps / dt / 1e6
     if rank == 0:
-        bps = 8 * sum(len(r) for r in allrecs) / samples_per_step
-        # ---- roofline of the dominant kernel instance (HIP events on the stream each launch ran on)
-        E, frac = cfg.maxnfunc, cfg.fraction
-        nopt = min(n, int(np.ceil(framesize * frac)))
-        ols_nmax = (16, 24, 32, 40, 48, 56, 64, 96)
-        def kname(kind, cls):
-            if kind == "ols":
-                return f"k_ols<{64 if cls < 3 else 256},{ols_nmax[cls]}>"
-            return f"k_lms<{cls}>"
-        cands = {}
-        for (kind, cls), (ms, launches, isteps) in ct.items():
-            cands[kname(kind, cls)] = (ms, launches, STAGE_BYTES[kind] * isteps)
-        cands["k_coder"] = (kt["coder"]["ms"], max(kt["coder"]["launches"], 1), (4 + bps / 8) * n * 2 * args.frames * args.steps)
-        dom = max(cands, key=lambda k: cands[k][0])
-        dms, dlaunch, dbytes = cands[dom]
-        avg_s = dms / 1e3 / max(dlaunch, 1)
-        achieved = dbytes / max(dlaunch, 1) / avg_s / 1e9 if avg_s > 0 else 0.0
-        out = {
-            "metric": "encode MSamples/s + bps, 16-bit/44.1kHz stereo, --high; 1/2/4/8 MI355X",
-            "value": value, "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.frames} frames/GPU x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
-                                   f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
-                       "frames_per_gpu": args.frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
-                       "concurrent_groups": ngroups,
-                       "parallelism": f"frames sharded over {world} GPU(s), RCCL record gather"},
-            "bps": bps, "x_realtime": (args.frames * world * args.seconds * args.steps) / dt,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launches": int(dlaunch), "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": dbytes / max(dlaunch, 1),
-                         "note": "latency/fp64-VALU-bound recurrences; HBM fraction is expected to be << 1 % (SURVEY.md 8d)"},
-            # the search never computes an identical channel evaluation twice within one batch (memo cleared
-            # by every staging, i.e. every step): requested vs answered without recomputation, this rank
-            "search_channel_evaluations": {"requested": ev_req, "shared_or_memoised": ev_memo},
-            "kernel_ms": {k: round(v["ms"], 2) for k, v in kt.items()},
-            "kernel_launches": {k: v["launches"] for k, v in kt.items()},
-            "kernel_instances_ms": {k: round(v[0], 2) for k, v in sorted(cands.items())},
-            "kernel_instances_launches": {k: int(v[1]) for k, v in sorted(cands.items())},
-            "kernel_instances_algorithmic_MB": {k: round(v[2] / 1e6, 1) for k, v in sorted(cands.items())},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(nthreads=args.dds_n)
-            out["cpu_baseline"] = cb
-            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        out = build_line(nsteps, dt, allrecs, last_recs, final=True)
+        add_kernel_report(out, nsteps)
+        latest["line"] = json.dumps(out)
         if args.verify:
             from oracle_api import Checker
             orc = Checker("orc")
-            ok = all(np.array_equal(orc.decode_frame(r, 2, max(n, 16))[0], f) for r, f in zip(recs, frames))
+            ok = all(np.array_equal(orc.decode_frame(r, 2, max(n, 16))[0], f) for r, f in zip(last_recs, frames))
             out["verified_lossless"] = bool(ok)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -148,11 +148,18 @@ int sacamd_debug_cost(sacamd_ctx *ctx, int kind, const int32_t *err, int n, doub
  * [0] analyse [1] tables [2] ols [3] lms [4] bias [5] cost [6] s2u/remap [7] coder; launches in [8..15] */
 int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
 
-/* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*8 + class)*3 + {0,1,2}] =
- * total ms (HIP events on the launch's stream), launches, item-steps processed; kind 0 = OLS capacity
- * classes (16,24,32 taps: k_ols<64,NMAX>; 40..96: k_ols<256,NMAX>), kind 1 = cascade
- * layout classes 0..6.  out has 48 entries. */
-int sacamd_class_times(sacamd_ctx *ctx, double *out48, int reset);
+/* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*8 + class)*4 + {0,1,2,3}] =
+ * total ms (HIP events on the launch's stream), launches, item-steps processed, algorithmic fp64 flops (FMA = 2,
+ * SURVEY.md 8d formula with each item's actual regressor length / tap counts); kind 0 = OLS capacity
+ * classes 0..7 (16,24,32 taps: k_ols<64,NMAX>; 40..96: k_ols<256,NMAX>), kind 1 = cascade layout classes 0..11
+ * (0..6: search layouts, 7..9: canonical-order layouts of the final pass).  out has (8 + 12) * 4 = 80 entries. */
+int sacamd_class_times(sacamd_ctx *ctx, double *out80, int reset);
+
+/* Progress of a running sacamd_encode_frames on this context; may be called from another thread while that call
+ * is in flight (the only entry point that may).  phase: 0 idle, 1 DDS search, 2 final prediction pass, 3 entropy
+ * coding; generation: DDS generations evaluated so far.  Lets a caller that keeps several contexts busy stagger
+ * them so that one batch's latency-bound final pass runs under another batch's search. */
+int sacamd_progress(const sacamd_ctx *ctx, int *phase, int *generation);
 
 /* debug: on!=0 enables per-section cycle counters in the predictor kernels (slows them slightly);
  * out16 (nullable, 16 entries) receives the counters of the last launch.  One-wave OLS kernel:

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "sacamd_frames_attach_s16_device", "sacamd_analyse", "sacamd_get_stats", "sacamd_evaluate",
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
-    "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version",
+    "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress",
 ]
 
 
@@ -289,11 +289,19 @@ class Context:
         return int(out[0]), int(out[1])
 
     def class_times(self, reset=True):
-        """per kernel instance: {(kind, class): (ms, launches, item_steps)}, kind 'ols' | 'lms'."""
-        out = np.zeros(48)
+        """per kernel instance: {(kind, class): (ms, launches, item_steps, fp64 flops)}, kind 'ols' | 'lms'."""
+        out = np.zeros(80)
         self._chk(self.lib.sacamd_class_times(self.h, _vp(out), int(reset)))
-        o = out.reshape(2, 8, 3)
-        return {(("ols", "lms")[k], c): tuple(o[k, c]) for k in range(2) for c in range(8) if o[k, c, 1] > 0}
+        o = out.reshape(20, 4)
+        res = {("ols", c): tuple(o[c]) for c in range(8) if o[c, 1] > 0}
+        res.update({("lms", c): tuple(o[8 + c]) for c in range(12) if o[8 + c, 1] > 0})
+        return res
+
+    def progress(self):
+        """(phase, generation) of an encode_frames call running on this context in another thread."""
+        ph, gen = c_int(0), c_int(0)
+        self.lib.sacamd_progress(self.h, byref(ph), byref(gen))
+        return ph.value, gen.value
 
     def kernel_times(self, reset=True):
         out = np.zeros(16)

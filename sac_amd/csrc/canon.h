@@ -97,6 +97,19 @@ SA_HD double dot_canon_n(A a, B b) {
   return total;
 }
 
+// the part of slmath::calc_s2pow (common/math.h:164-191) that std::transform_reduce handles: the < 4 elements
+// after the AVX2 chains, or all n < 8 elements of a short vector; terms are pw * (x * x)
+SA_HD double tr_s2pow(const double *x, const double *pw, int n) {
+  double init = 0.0;
+  while (n >= 4) {
+    const double v1 = fma(x[1] * x[1], pw[1], (x[0] * x[0]) * pw[0]);
+    const double v2 = fma(x[3] * x[3], pw[3], (x[2] * x[2]) * pw[2]);
+    init = init + (v1 + v2);
+    x += 4; pw += 4; n -= 4;
+  }
+  return fold_add(init, n, [&](int k) { return x[k] * x[k]; }, [&](int k) { return pw[k]; });
+}
+
 SA_HD double sgnd(double x) { return (double)((x > 0) - (x < 0)); }
 SA_HD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 SA_HD int clampi32(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,7 +82,7 @@ enum { FAM_ANALYSE = 0, FAM_TABLES, FAM_OLS, FAM_LMS, FAM_BIAS, FAM_COST, FAM_S2
 struct TimedSpan { int fam; hipEvent_t a, b; bool shared_a = false; };   // shared_a: a belongs to another span
 // per-launch timing of one predictor kernel instance (events on the launch's own stream);
 // SACAMD_TRACE=1 additionally prints each launch on stderr
-struct TraceSpan { char label[64]; int kind, cls; double item_steps; hipEvent_t a, b; };
+struct TraceSpan { char label[64]; int kind, cls; double item_steps, flops; hipEvent_t a, b; };
 
 }  // namespace
 
@@ -109,7 +110,8 @@ struct sacamd_ctx {
   DevBuf<unsigned char> d_used;
   // predictor scratch
   DevBuf<WorkItem> d_items;
-  DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist;
+  DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist, d_nf;   // d_nf: per work-item "prediction not finite" flags of the last run_predict
+  std::vector<int> h_nf;
   DevBuf<double> d_tab, d_p, d_q, d_cost;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
   DevBuf<long long> d_off;
   // final pass products (per frame, channel): offsets (f*nch+ch)*ch_stride
@@ -148,8 +150,12 @@ struct sacamd_ctx {
   std::vector<TraceSpan> trace;
   bool tracing = false;
   // [kind 0 = OLS classes 0..7, kind 1 = cascade classes 0..2][class] -> ms, launches, item-steps
-  double cls_ms[2][kNumOlsClasses] = {}, cls_item_steps[2][kNumOlsClasses] = {};
-  long long cls_launches[2][kNumOlsClasses] = {};
+  static constexpr int kClsMax = 12;   // >= kNumOlsClasses, kNumLmsClasses
+  double cls_ms[2][kClsMax] = {}, cls_item_steps[2][kClsMax] = {}, cls_flops[2][kClsMax] = {};
+  // progress of sacamd_encode_frames, readable from another thread (sacamd_progress): phase 0 idle, 1 search,
+  // 2 final prediction pass, 3 entropy coding; generation = DDS generations evaluated so far
+  std::atomic<int> phase{0}, generation{0};
+  long long cls_launches[2][kClsMax] = {};
   double fam_ms[FAM_COUNT] = {0};
   long long fam_launches[FAM_COUNT] = {0};
 };
@@ -190,7 +196,7 @@ void collect_spans(sacamd_ctx *c) {
   for (auto &t : c->trace) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
-      c->cls_ms[t.kind][t.cls] += ms; c->cls_launches[t.kind][t.cls]++; c->cls_item_steps[t.kind][t.cls] += t.item_steps;
+      c->cls_ms[t.kind][t.cls] += ms; c->cls_launches[t.kind][t.cls]++; c->cls_item_steps[t.kind][t.cls] += t.item_steps; c->cls_flops[t.kind][t.cls] += t.flops;
       if (c->tracing) std::fprintf(stderr, "[sacamd trace] %s %.3f ms\n", t.label, ms);
     }
     (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
@@ -201,10 +207,10 @@ void collect_spans(sacamd_ctx *c) {
 // optional per-launch trace on an arbitrary stream
 struct Trace {
   sacamd_ctx *c; hipStream_t st; TraceSpan t; bool on;
-  Trace(sacamd_ctx *c_, hipStream_t st_, const char *what, int cls, int count, int n, double item_steps = 0.0) : c(c_), st(st_), on(count > 0) {
+  Trace(sacamd_ctx *c_, hipStream_t st_, const char *what, int cls, int count, int n, double item_steps = 0.0, double flops = 0.0) : c(c_), st(st_), on(count > 0) {
     if (!on) return;
     std::snprintf(t.label, sizeof(t.label), "%s class %d items %d steps %d", what, cls, count, n);
-    t.kind = what[0] == 'o' ? 0 : 1; t.cls = cls; t.item_steps = item_steps;
+    t.kind = what[0] == 'o' ? 0 : 1; t.cls = cls; t.item_steps = item_steps; t.flops = flops;
     (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
     (void)hipEventRecord(t.a, st);
   }
@@ -217,7 +223,7 @@ int sync_stream(sacamd_ctx *c) {
   return 0;
 }
 
-PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride, c->d_prof}; }
+PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride, c->d_prof, c->d_olskeep.p}; }
 
 // ------------------------------------------------------------ work-item construction
 struct Cand { int frame; const float *coefs; int start, n; bool optimize; int optk; };
@@ -228,7 +234,7 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
   for (size_t ci = 0; ci < cands.size(); ci++) {
     const Cand &cd = cands[ci];
     if (cd.frame < 0 || cd.frame >= c->nframes) return fail(c, SACAMD_ERR_ARG, "candidate frame out of range");
-    ChanParam cp[2]; int ch_ref = 0;
+    ChanParam cp[2] = {}; int ch_ref = 0;     // value-initialised: the memo keys hash the raw bytes, padding included
     map_profile(cd.coefs, cd.optimize, cd.optk, c->nch, &c->h_stats[(size_t)cd.frame * c->nch], cp, &ch_ref);
     for (int slot = 0; slot < c->nch; slot++) {
       WorkItem it;
@@ -246,7 +252,7 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
       it.ols_class = 0;
       while (p.n_ols > kOlsClassMax[it.ols_class]) it.ols_class++;
       const int *vn = p.vn;
-      it.lms_class = lms_class_for(vn);
+      it.lms_class = lms_class_for(vn, /*canon=*/!cd.optimize);   // the final pass (k = 1, what the decoder recomputes) sums in slmath::dot order
       it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab;
       off_p += cd.n;
       for (int s = 0; s < 4; s++) off_tab += 2LL * vn[s];
@@ -254,6 +260,18 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
     }
   }
   return 0;
+}
+
+// algorithmic fp64 flops of one work-item (FMA = 2), SURVEY.md 8(d): OLS regressor dot 2n, covariance / b update
+// 2n(n+1) + 4n, LDL^T factor + two triangular solves n^3/2 + 2n^2 + 6n every k-th step; cascade 8 flop + 2 clamps
+// per tap and about 200 for RLS, mixers and blend
+double ols_flops(const WorkItem &it) {
+  const double n = it.p.n_ols;
+  return (double)it.n * (2 * n + 2 * n * (n + 1) + 4 * n + (n * n * n / 2 + 2 * n * n + 6 * n) / it.p.k);
+}
+double lms_flops(const WorkItem &it) {
+  const double taps = it.p.vn[0] + it.p.vn[1] + it.p.vn[2] + it.p.vn[3];
+  return (double)it.n * (10 * taps + 200);
 }
 
 // run the three predictor stages for `items`; residual -> d_err (+ d_pred when want_pred)
@@ -268,6 +286,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, c->d_p.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_q.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_err.ensure((size_t)tot_p + 512));
+  HIPCHK(c, c->d_nf.ensure(count));
+  HIPCHK(c, hipMemsetAsync(c->d_nf.p, 0, sizeof(int) * count, c->stream));
   // The OLS stage of a work-item depends only on the PCM and on the OLS part of its parameters.
   // DDS candidates of one frame mostly differ in a few coefficients, so many items of a launch have
   // identical OLS stages: run each distinct one once (the "leader") and let the others' cascade
@@ -315,11 +335,11 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       if (slot >= 0) {
         e[slot].stamp = c->ols_stamp;
         const long long idx = (long long)(e - c->ols_kept.data()) + slot;
-        items[i].off_pin = (c->d_olskeep.p + idx * c->ols_keep_len) - c->d_p.p;     // offset relative to the p_lpc buffer
+        items[i].off_pin = idx * c->ols_keep_len; items[i].pin_kept = 1;           // offset into the kept-stream buffer
       }
     }
   }
-  for (int i = 0; i < count; i++) if (ols_lead[i] != i) items[i].off_pin = items[ols_lead[i]].off_pin;
+  for (int i = 0; i < count; i++) if (ols_lead[i] != i) { items[i].off_pin = items[ols_lead[i]].off_pin; items[i].pin_kept = items[ols_lead[i]].pin_kept; }
   if (want_pred) HIPCHK(c, c->d_pred.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
@@ -384,8 +404,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     hipStream_t st = c->cls_stream[k];
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     {
-      double isteps = 0; for (int i : idx_ols[k]) isteps += items[i].n;
-      Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps);
+      double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
+      Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
       launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p);
     }
     HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
@@ -402,8 +422,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     if (!lms_used[si]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); lms_used[si] = true; }
     for (int k = ll.group ? kFastOls : 0; k < (ll.group ? kNumOlsClasses : kFastOls); k++)
       if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
-    double isteps = 0; for (int i = 0; i < ll.count; i++) isteps += items[flat[ll.first + i]].n;
-    Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps);
+    double isteps = 0, fl = 0; for (int i = 0; i < ll.count; i++) { isteps += items[flat[ll.first + i]].n; fl += lms_flops(items[flat[ll.first + i]]); }
+    Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps, fl);
     launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p, c->d_q.p);
   }
   for (int si = kNumOlsClasses; si < kMark; si++)
@@ -414,8 +434,10 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   c->spans.push_back(sp_ols); c->spans.push_back(sp_lms);
   c->fam_launches[FAM_OLS]++; c->fam_launches[FAM_LMS]++;
   { Span sp(c, FAM_BIAS);
-    launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr); }
+    launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, want_pred ? c->d_pred.p : nullptr, c->d_nf.p); }
   HIPCHK(c, hipGetLastError());
+  c->h_nf.assign(count, 0);      // valid after the caller's next stream synchronisation
+  HIPCHK(c, hipMemcpyAsync(c->h_nf.data(), c->d_nf.p, sizeof(int) * count, hipMemcpyDeviceToHost, c->stream));
   return 0;
 }
 
@@ -490,7 +512,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
-  c->d_pred.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
+  c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();
@@ -678,6 +700,7 @@ API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const i
       r = run_costs(c, cfg->optimize_cost, off, n, c->d_err.p, tv);
     }
     if (r) return r;
+    for (size_t i = 0; i < todo.size(); i++) if (c->h_nf[i]) tv[i] = INFINITY;   // the reference throws here (cascade.h:40-41): such a candidate never wins
     for (size_t i = 0; i < todo.size(); i++) c->eval_cache.emplace(todo_key[i], tv[i]);
     for (size_t i = 0; i < items.size(); i++) if (src[i] >= 0) cv[i] = tv[src[i]];
   }
@@ -726,6 +749,8 @@ API int sacamd_predict_final(sacamd_ctx *c, const sacamd_cfg *cfg, const float *
   HIPCHK(c, hipMemcpyAsync(c->h_maxbpn.data(), c->d_maxbpn.p, sizeof(int) * off.size(), hipMemcpyDeviceToHost, c->stream));
   r = sync_stream(c);
   if (r) return r;
+  for (size_t i = 0; i < items.size(); i++)
+    if (c->h_nf[i]) return fail(c, SACAMD_ERR_NONFINITE, "final pass: predictor of frame " + std::to_string(items[i].frame) + " is not finite (pred/cascade.h:40-41)");
   c->final_coefs.assign(coefs, coefs + (size_t)c->nframes * kNumCoefs);
   c->final_done = true; c->encoded = false;
   return 0;
@@ -776,7 +801,7 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_q.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
   }
-  { Span sp(c, FAM_BIAS); launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, c->d_pred.p); }
+  { Span sp(c, FAM_BIAS); launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, c->d_pred.p, nullptr); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   collect_spans(c);
   HIPCHK(c, hipGetLastError());
@@ -870,6 +895,13 @@ API int sacamd_plan_subframes(sacamd_ctx *c, const int32_t *pcm, long long ch_st
   return sacamd_subframes_from_states(state.data(), blen.data(), nblocks, min_frame_length, out, cap, count);
 }
 
+API int sacamd_progress(const sacamd_ctx *c, int *phase, int *generation) {
+  if (!c) return SACAMD_ERR_ARG;
+  if (phase) *phase = c->phase.load(std::memory_order_relaxed);
+  if (generation) *generation = c->generation.load(std::memory_order_relaxed);
+  return 0;
+}
+
 API int sacamd_eval_stats(sacamd_ctx *c, long long *out2, int reset) {
   if (!c || !out2) return SACAMD_ERR_ARG;
   out2[0] = c->eval_items; out2[1] = c->eval_hits;
@@ -880,11 +912,12 @@ API int sacamd_eval_stats(sacamd_ctx *c, long long *out2, int reset) {
 API int sacamd_class_times(sacamd_ctx *c, double *out, int reset) {
   if (!c || !out) return SACAMD_ERR_ARG;
   collect_spans(c);
+  static_assert(kNumOlsClasses == 8 && kNumLmsClasses <= sacamd_ctx::kClsMax, "sacamd_class_times layout");
   for (int kind = 0; kind < 2; kind++)
-    for (int k = 0; k < kNumOlsClasses; k++) {
-      double *o = out + (kind * kNumOlsClasses + k) * 3;
-      o[0] = c->cls_ms[kind][k]; o[1] = (double)c->cls_launches[kind][k]; o[2] = c->cls_item_steps[kind][k];
-      if (reset) { c->cls_ms[kind][k] = 0; c->cls_launches[kind][k] = 0; c->cls_item_steps[kind][k] = 0; }
+    for (int k = 0; k < (kind ? sacamd_ctx::kClsMax : kNumOlsClasses); k++) {
+      double *o = out + (kind * kNumOlsClasses + k) * 4;
+      o[0] = c->cls_ms[kind][k]; o[1] = (double)c->cls_launches[kind][k]; o[2] = c->cls_item_steps[kind][k]; o[3] = c->cls_flops[kind][k];
+      if (reset) { c->cls_ms[kind][k] = 0; c->cls_launches[kind][k] = 0; c->cls_item_steps[kind][k] = 0; c->cls_flops[kind][k] = 0; }
     }
   return 0;
 }

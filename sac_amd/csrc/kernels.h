@@ -10,6 +10,7 @@ struct PcmView {            // centred planar int32 PCM of the staged batch
   const int *pcm;
   long long frame_stride, ch_stride;
   unsigned long long *prof;   // optional: 8 section cycle counters of the OLS kernel (debug)
+  double *keep;               // kept p_lpc streams of earlier search generations (WorkItem::pin_kept), nullable
 };
 
 // ---- analyse (kernels_misc.hip)
@@ -24,12 +25,12 @@ void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab);
 void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p);
 struct LmsRingCap { int c[4]; };   // per-stage history ring capacity (doubles) of one launch
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc);
-int lms_class_for(const int *vn);               // cascade layout class for stage lengths vn[4]
+int lms_class_for(const int *vn, bool canon);   // cascade layout class for stage lengths vn[4]; canon: slmath::dot summation order (final pass)
 int lms_max_wg_per_cu(int lms_class);          // register-file bound on resident workgroups per CU
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, const double *d_p /*p_lpc in*/, double *d_q /*p_lpc+p_lms out*/);
 void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
-                 const double *d_p, int *d_err, int *d_pred /*nullable*/);
+                 const double *d_p, int *d_err, int *d_pred /*nullable*/, int *d_nonfinite /*[count]: set to 1 where the prediction was not finite*/);
 // ---- costs / s2u (kernels_misc.hip)
 void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_off, const int *d_n, int count,
                  int *d_hist_scratch, double *d_cost);

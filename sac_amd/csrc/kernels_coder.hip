@@ -1,6 +1,7 @@
 // sac_amd/csrc/kernels_coder.hip -- gfx950 kernels: bitplane/SSE range coder streams and the
 // sparse-PCM residual remap (Remap::Map + CalcRemapError, map.cpp:175-187, libsac.cpp:230-251).
 #include "coder.h"
+#include <atomic>
 #include "kernels.h"
 
 namespace sacamd {
@@ -48,8 +49,16 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv, unsigned char *d_state,
                   size_t state_stride, unsigned char *d_out, int *d_len) {
   if (count <= 0) return;
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::bytes(kCoderStreamsPerWg)); once = true; }
+  {   // per DEVICE opt-in to > 64 KB dynamic LDS (idempotent; launchers may be called from several host threads)
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      if (hipFuncSetAttribute((const void *)k_coder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::bytes(kCoderStreamsPerWg)) != hipSuccess) return;
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
   // the fewest streams per CU that still keep every stream resident at once (256 CUs): one-stream
   // workgroups (two per CU) up to 512 streams, then one workgroup per CU with three to six streams
   // (a serial stream issues an instruction every few cycles, so two of them share a SIMD well;

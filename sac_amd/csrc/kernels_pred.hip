@@ -6,7 +6,23 @@
 #include "pred_ols.h"
 #include "pred_tables.h"
 
+#include <atomic>
+
 namespace sacamd {
+
+// Opt a kernel in to more than 64 KB of dynamic LDS once per DEVICE (the attribute is per device; contexts on
+// different devices, and launchers called from several host threads, share these functions).  Idempotent, so a
+// race between two first launches is harmless.
+static hipError_t ensure_dyn_lds(const void *fn, size_t bytes, std::atomic<unsigned long long> &done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 // ------------------------------------------------------------------ NLMS tables
 // grid (work-item, stage); mutab/powtab per tap, then the in-order sum of powtab (ls.h:37-42)
@@ -51,16 +67,17 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_pin, smem, v.prof);
-  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_pin, smem, v.prof);
-  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, pbuf + it.off_pin, smem, v.prof);   // off_pin: where this item's p_lpc lives
+  double *out = (it.pin_kept ? v.keep : pbuf) + it.off_pin;   // off_pin: where this item's p_lpc lives
+  if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
+  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
+  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
 }
 
 template <int NL, int NMAX>
 static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
-  static bool once = false;
+  static std::atomic<unsigned long long> done{0};
   const size_t bytes = NL == 64 ? OlsLdsFast::bytes(NMAX) : ((NL == 256 && NMAX > 64) ? ols_panel2_lds_bytes(NMAX) : ols_panel_lds_bytes(NMAX, NL / 64));
-  if (!once) { (void)hipFuncSetAttribute((const void *)k_ols<NL, NMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); once = true; }
+  if (ensure_dyn_lds((const void *)k_ols<NL, NMAX>, bytes, done) != hipSuccess) return;   // the launch below would fail too; hipGetLastError reports it
   hipLaunchKernelGGL((k_ols<NL, NMAX>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_p);
 }
 
@@ -98,6 +115,10 @@ using LmsE = LmsClass<20, 4, 5, 1>;
 // default bench run), leaving ~10 % to the 30-slot layouts
 using LmsX = LmsClass<6, 10, 4, 2>;
 using LmsY = LmsClass<13, 5, 3, 1>;
+// canonical-order layouts of the final pass (pred_lms.h, CANON): odd slot counts (bank-conflict-free strided
+// ring reads); 7: (2304, 1280, 768, 256) taps on 256 lanes, 8: twice that on 512 lanes, 9: the profile maximum
+using LmsK = LmsClass<9, 5, 3, 1>;
+using LmsL = LmsClass<17, 9, 5, 3>;
 template <int CLS> struct LmsCfg;
 template <> struct LmsCfg<0> { using C = LmsA; static constexpr int NL = 256, MINB = 1; };
 template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MINB = 2; };
@@ -106,6 +127,9 @@ template <> struct LmsCfg<3> { using C = LmsD; static constexpr int NL = 256, MI
 template <> struct LmsCfg<4> { using C = LmsE; static constexpr int NL = 256, MINB = 2; };
 template <> struct LmsCfg<5> { using C = LmsX; static constexpr int NL = 256, MINB = 2; };
 template <> struct LmsCfg<6> { using C = LmsY; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 512, MINB = 1; };
+template <> struct LmsCfg<9> { using C = LmsL; static constexpr int NL = 512, MINB = 1; };
 
 template <int CLS>
 __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {
@@ -118,16 +142,17 @@ __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(cons
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  lms_stage<ExecDev<NL>, C>(ex, p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof);
+  lms_stage<ExecDev<NL>, C, (CLS >= kLmsCanonFirst)>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof);
 }
 
 template <int CLS>
 static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, LmsRingCap rc, PcmView v, const double *d_tab, const double *d_p, double *d_q) {
   constexpr int NL = LmsCfg<CLS>::NL;
   using C = typename LmsCfg<CLS>::C;
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void *)k_lms<CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LmsLds<NL, C>::bytes()); once = true; }
-  const size_t bytes = LmsLds<NL, C>::bytes(rc.c);
+  static std::atomic<unsigned long long> done{0};
+  constexpr bool CANON = CLS >= kLmsCanonFirst;
+  if (ensure_dyn_lds((const void *)k_lms<CLS>, LmsLds<NL, C, CANON>::bytes(), done) != hipSuccess) return;
+  const size_t bytes = LmsLds<NL, C, CANON>::bytes(rc.c);
   hipLaunchKernelGGL((k_lms<CLS>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_tab, d_p, d_q, rc);
 }
 
@@ -139,13 +164,21 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 4: return LmsLds<256, LmsE>::bytes(rc.c);
     case 5: return LmsLds<256, LmsX>::bytes(rc.c);
     case 6: return LmsLds<256, LmsY>::bytes(rc.c);
+    case 7: return LmsLds<256, LmsK, true>::bytes(rc.c);
+    case 8: return LmsLds<512, LmsK, true>::bytes(rc.c);
+    case 9: return LmsLds<512, LmsL, true>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
   }
 }
 
 // first layout, in order of cost, whose per-stage slots hold the item's stage lengths
-int lms_class_for(const int *vn) {
+int lms_class_for(const int *vn, bool canon) {
   auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
+  if (canon) {
+    if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 7;
+    if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 8;
+    return 9;
+  }
   if (fits(256, LmsA::c0, LmsA::c1, LmsA::c2, LmsA::c3)) return 0;
   if (fits(256, LmsX::c0, LmsX::c1, LmsX::c2, LmsX::c3)) return 5;
   if (fits(256, LmsY::c0, LmsY::c1, LmsY::c2, LmsY::c3)) return 6;
@@ -156,7 +189,7 @@ int lms_class_for(const int *vn) {
 }
 
 // register-file bound on resident workgroups per CU (237 / 256 / 256 registers, 4 / 4 / 8 waves)
-int lms_max_wg_per_cu(int lms_class) { return lms_class == 2 ? 1 : 2; }
+int lms_max_wg_per_cu(int lms_class) { return (lms_class == 2 || lms_class >= 8) ? 1 : 2; }
 
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, const double *d_p, double *d_q) {
@@ -168,6 +201,9 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 4: launch_lms_c<4>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 5: launch_lms_c<5>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 6: launch_lms_c<6>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 7: launch_lms_c<7>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 8: launch_lms_c<8>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 9: launch_lms_c<9>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     default: launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
   }
 }
@@ -176,7 +212,7 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
 constexpr int kBiasSlabStride = kBiasSlabDoubles + 1;   // odd stride: spread lanes over LDS banks
 
 __global__ __launch_bounds__(64) void k_bias(const WorkItem *items, int count, PcmView v, const FrameStatsD *stats, int nch,
-                                              const double *pbuf, int *errbuf, int *predbuf) {
+                                              const double *pbuf, int *errbuf, int *predbuf, int *nonfinite) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= count) return;
@@ -185,14 +221,14 @@ __global__ __launch_bounds__(64) void k_bias(const WorkItem *items, int count, P
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   double *tables = reinterpret_cast<double *>(smem) + (size_t)threadIdx.x * kBiasSlabStride;
   const int mean = stats[it.frame * nch + it.ch_self].mean;
-  bias_stage(p, self, it.n, pbuf + it.off_p, mean, errbuf + it.off_err, predbuf ? predbuf + it.off_err : nullptr, tables);
+  bias_stage(p, self, it.n, pbuf + it.off_p, mean, errbuf + it.off_err, predbuf ? predbuf + it.off_err : nullptr, tables, nonfinite ? nonfinite + i : nullptr);
 }
 
 void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
-                 const double *d_p, int *d_err, int *d_pred) {
+                 const double *d_p, int *d_err, int *d_pred, int *d_nonfinite) {
   if (count <= 0) return;
   const size_t bytes = (size_t)64 * kBiasSlabStride * sizeof(double);
-  hipLaunchKernelGGL(k_bias, dim3((count + 63) / 64), dim3(64), bytes, s, d_items, count, v, d_stats, nch, d_p, d_err, d_pred);
+  hipLaunchKernelGGL(k_bias, dim3((count + 63) / 64), dim3(64), bytes, s, d_items, count, v, d_stats, nch, d_p, d_err, d_pred, d_nonfinite);
 }
 
 }  // namespace sacamd

@@ -17,7 +17,8 @@ constexpr int kStages = 4;
 // regressor-length capacity of each OLS kernel instance; the last one is the two-wave generic path
 constexpr int kNumOlsClasses = 8;
 constexpr int kOlsClassMax[kNumOlsClasses] = {16, 24, 32, 40, 48, 56, 64, 96};
-constexpr int kNumLmsClasses = 7;
+constexpr int kNumLmsClasses = 10;   // 0..6 search layouts (free summation order), 7..9 canonical-order layouts of the final pass
+constexpr int kLmsCanonFirst = 7;
 
 struct ChanParam {
   // OLS
@@ -44,10 +45,12 @@ struct WorkItem {
   int ch_other;       // file channel of the "other" regressor part (== ch_self for mono)
   int slot;           // predictor slot 0/1
   int start, n;       // window [start, start+n) inside the frame
-  int lms_class;      // register layout class of the cascade kernel (kernels_pred.hip, LmsCfg)
+  int lms_class;      // register layout class of the cascade kernel (kernels_pred.hip, LmsCfg); >= kLmsCanonFirst: canonical summation order
   int ols_class;      // index into kOlsClassMax (LDS capacity class of the OLS kernel)
   long long off_p;    // doubles: this item's p_lpc stream in the OLS buffer and its p_lpc+p_lms stream in the cascade buffer [n]
   long long off_pin;  // doubles: where the cascade reads p_lpc (== off_p unless the OLS result is shared with another item)
+  int pin_kept;       // 1: off_pin is relative to the context's buffer of kept search-window streams, not to the p_lpc buffer
+  int pad_;
   long long off_err;  // int32 residual [n]
   long long off_tab;  // doubles: per stage {mutab[vn], powtab[vn]}, stages back to back
   double sum_powtab[kStages];   // filled by the table kernel

@@ -17,9 +17,11 @@ namespace sacamd {
 constexpr int kBiasCtx = 56;                       // 32 (ctx0) + 8 (ctx1) + 16 (ctx2)
 constexpr int kBiasSlabDoubles = 2 * kBiasCtx + 12;   // {cnt,val} pairs + 4x3 SSLMS mixer weights
 
-// tables: this lane's slab of kBiasSlabDoubles doubles.  err/pred may be null.
+// tables: this lane's slab of kBiasSlabDoubles doubles.  err/pred may be null.  *nonfinite (nullable) is set to 1
+// when a prediction is not finite -- where the reference throws (pred/cascade.h:40-41) the caller reports
+// SACAMD_ERR_NONFINITE (final pass) or an infinite cost (search).
 SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *psum, int mean,
-                      int *err, int *pred, double *tables) {
+                      int *err, int *pred, double *tables, int *nonfinite = nullptr) {
   double *cnt = tables, *val = tables + kBiasCtx;
   for (int i = 0; i < kBiasCtx; i++) { cnt[i] = 4.0; val[i] = 0.0; }
   double *mixw = tables + 2 * kBiasCtx;    // [4][3]
@@ -32,6 +34,7 @@ SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *
 
   for (int t = 0; t < n; t++) {
     const double px = psum[t];
+    if (nonfinite && !(fabs(px) <= 1.79769313486231570815e308)) *nonfinite = 1;
     // CalcContext (bias.h:64-113)
     const int b0 = hin0 > px ? 0 : 1;
     const int b2 = hd0 < 0 ? 0 : 1, b3 = hd1 < 0 ? 0 : 1, b4 = hd2 < 0 ? 0 : 1;

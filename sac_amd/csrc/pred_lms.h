@@ -12,10 +12,19 @@
 // step t" (the update needs the pre-push history, which is the post-push history shifted by
 // one), then a wave-shuffle / LDS reduction, then the serial mixer chain on wave 0.
 //
-// Arithmetic: the per-tap element operations are the reference's (explicit fma); the N-term
-// dot / power sums are reduced in lane-then-tree order, NOT slmath::dot's AVX2 order -- a
-// ~1e-14 relative perturbation of p_lms (tolerance 1e-9 in the tests).  The
-// small dots of the serial chain use the canonical order (canon.h).
+// Arithmetic: the per-tap element operations are the reference's (explicit fma); the small dots of
+// the serial chain use the canonical order (canon.h).  The N-term dot / power sums come in two forms:
+//   CANON = false (search evaluations, k = optk): reduced in lane-then-tree order, NOT slmath::dot's
+//     AVX2 order -- a ~1e-14 relative perturbation of p_lms that only moves search costs.
+//   CANON = true (the final pass, whose residual goes into the bitstream and which the reference
+//     decoder recomputes): exactly slmath::dot / calc_s2pow (common/math.h:130-191): 8 resp. 4
+//     strided serial FMA chains, (s1+s2), ((b0+b1)+b2)+b3, then the transform_reduce tail -> p_lms is
+//     bit-identical to the reference's.  Layout for that: the taps of chain c are spread over the
+//     lanes of one wave in blocks of J consecutive chain positions (lane m holds positions
+//     mJ..mJ+J-1), the running sum hops from lane to lane (DPP wave_shr:1) and every lane adds its J
+//     terms with dependent FMAs -- a systolic pass whose depth is the chain length, which is the
+//     floor any implementation of that summation order has.  The history rings are padded by one
+//     element per eight so that the strided reads are bank-conflict free for odd J.
 #pragma once
 #include "canon.h"
 #include "libm_port.h"
@@ -48,8 +57,10 @@ SA_HD double dot_canon_m(int m, A a, B b) {
   }
 }
 
-template <int NL, class C>
+template <int NL, class C, bool CANON = false>
 struct LmsLds {
+  SA_HD static constexpr int ridx(int a) { return CANON ? a + (a >> 3) : a; }   // physical ring index
+  double *csum, *psum, *tailw, *tailpw;   // CANON: chain sums [2][4][8], [2][4][4]; tail weights [2][4][8]; tail powtab [4][8]
   double *ring[4];
   double *part;     // [2][NL/64][8]
   double *bc;       // [8]: wgrad[4], unused
@@ -66,7 +77,8 @@ struct LmsLds {
   // footprint follows the taps actually in use, not the register-capacity class
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
-    for (int s = 0; s < 4; s++) d += (size_t)ringcap[s] + 1;      // + the mirror element ring[cap] == ring[0]
+    for (int s = 0; s < 4; s++) d += (size_t)ridx(ringcap[s]) + 1;      // + the mirror element ring[cap] == ring[0]
+    if (CANON) d += 64 + 32 + 64 + 32;
     d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + NL * sizeof(int) + 16;
   }
@@ -76,7 +88,9 @@ struct LmsLds {
   }
   SA_HD void carve(char *base, const int *ringcap) {
     double *d = reinterpret_cast<double *>(base);
-    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ringcap[s] + 1; }
+    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ridx(ringcap[s]) + 1; }
+    csum = psum = tailw = tailpw = nullptr;
+    if (CANON) { csum = d; d += 64; psum = d; d += 32; tailw = d; d += 64; tailpw = d; d += 32; }
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 8;
     pin = d; d += NL; pout = d; d += NL;
@@ -89,18 +103,61 @@ struct LmsLds {
 };
 
 
-template <class E, class C>
+// tail of slmath::dot handled by std::transform_reduce (< 8 elements), operands through getters
+template <class A, class B>
+SA_HD double tr_dot_g(int n, A a, B b) {
+  double init = 0.0;
+  int o = 0;
+  if (n >= 4) {
+    const double v1 = fma(a(1), b(1), a(0) * b(0));
+    const double v2 = fma(a(3), b(3), a(2) * b(2));
+    init = init + (v1 + v2);
+    o = 4;
+  }
+  if (n - o >= 2) { init = init + a(o) * b(o); init = init + a(o + 1) * b(o + 1); o += 2; }
+  if (o < n) init = fma(a(o), b(o), init);
+  return init;
+}
+// same for calc_s2pow: terms pw * (x * x)
+template <class A, class B>
+SA_HD double tr_s2pow_g(int n, A x, B pw) {
+  double init = 0.0;
+  int o = 0;
+  if (n >= 4) {
+    const double x0 = x(0), x1 = x(1), x2 = x(2), x3 = x(3);
+    const double v1 = fma(x1 * x1, pw(1), (x0 * x0) * pw(0));
+    const double v2 = fma(x3 * x3, pw(3), (x2 * x2) * pw(2));
+    init = init + (v1 + v2);
+    o = 4;
+  }
+  if (n - o >= 2) { const double xa = x(o), xb = x(o + 1); init = init + (xa * xa) * pw(o); init = init + (xb * xb) * pw(o + 1); o += 2; }
+  if (o < n) { const double xa = x(o); init = fma(xa * xa, pw(o), init); }
+  return init;
+}
+
+template <class E, class C, bool CANON = false>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
                      const int *self, int n, const double *pin_g, double *pout_g, char *lds_base, const int *ringcap,
                      unsigned long long *prof = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
   constexpr int kLmsChunk = NL;   // samples staged per global<->LDS exchange: one element per lane
-  LmsLds<NL, C> L;
+  LmsLds<NL, C, CANON> L;
   L.carve(lds_base, ringcap);
+  auto ridx = [](int a) { return LmsLds<NL, C, CANON>::ridx(a); };
+  // CANON geometry: the 8 dot chains are spread CPW per wave over LPC lanes each; the 4 power-sum chains
+  // run on waves 0..3, 64 lanes each, with SMUL times the slots per lane
+  static_assert(!CANON || NL == 256 || NL == 512, "canonical layout: 4 or 8 waves");
+  constexpr int CPW = CANON ? 8 / NW : 1, LPC = 64 / CPW, SMUL = CANON ? NL / 256 : 1;
+  constexpr int NX = CANON ? C::total : 1;
 
-  typename E::template Reg<DArr<C::total>> W, MT, PT;
+  typename E::template Reg<DArr<C::total>> W, MT;
+  typename E::template Reg<DArr<C::total * SMUL>> PT;
   typename E::template Reg<DArr<8>> acc;
+  typename E::template Reg<DArr<CANON ? 4 : 1>> Wt, MTt;        // CANON: the chain's tail tap (taps beyond 8*floor(n/8)) of lanes m == 0
+  typename E::template Reg<DArr<NX>> XD;                        // CANON: history values of this lane's dot-chain taps
+  typename E::template Reg<DArr<NX * SMUL>> XX;                 // CANON: squared history values of this lane's power-chain taps
+  typename E::template Reg<double> sd[4], sq[4], hop;           // CANON: running chain sums
 
   int ns[4], cap[4], pos[4];
   for (int s = 0; s < 4; s++) { ns[s] = p.vn[s]; cap[s] = ns[s] + 1; pos[s] = 0; }
@@ -121,15 +178,37 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     const double *tp = tab;
     for (int s = 0; s < 4; s++) {
       const int f = C::first(s);
-      for (int j = 0; j < C::slots(s); j++) {
-        const int tap = j * NL + l;
-        const bool on = tap < ns[s];
-        W[l].v[f + j] = 0.0;
-        MT[l].v[f + j] = on ? tp[tap] : 0.0;
-        PT[l].v[f + j] = on ? tp[ns[s] + tap] : 0.0;
+      if constexpr (!CANON) {
+        for (int j = 0; j < C::slots(s); j++) {
+          const int tap = j * NL + l;
+          const bool on = tap < ns[s];
+          W[l].v[f + j] = 0.0;
+          MT[l].v[f + j] = on ? tp[tap] : 0.0;
+          PT[l].v[f + j] = on ? tp[ns[s] + tap] : 0.0;
+        }
+      } else {
+        // dot layout: lane (wave w, half, m) owns positions m*J..m*J+J-1 of chain c = w*CPW + half, i.e. taps 8k + c;
+        // positions >= K8 = n/8 are empty.  The chain's tail tap 8*K8 + c (if < n) sits in the extra slot of lane m == 0.
+        const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
+        const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0, K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
+        for (int j = 0; j < C::slots(s); j++) {
+          const int k = m * C::slots(s) + j;
+          W[l].v[f + j] = 0.0;
+          MT[l].v[f + j] = k < K8 ? tp[8 * k + c] : 0.0;
+        }
+        const int tt = 8 * K8 + c;
+        Wt[l].v[s] = 0.0;
+        MTt[l].v[s] = (m == 0 && tt < ns[s]) ? tp[tt] : 0.0;
+        // power-sum layout: lane m4 of wave c4 < 4 owns positions m4*JS.. of chain c4, taps 4k + c4, K4 = n/4 positions
+        const int c4 = l >> 6;
+        for (int j = 0; j < C::slots(s) * SMUL; j++) {
+          const int k = lw * (C::slots(s) * SMUL) + j;
+          PT[l].v[f * SMUL + j] = (c4 < 4 && k < K4) ? tp[ns[s] + 4 * k + c4] : 0.0;
+        }
+        if (l < 8) { const int ti = 4 * K4 + l; L.tailpw[s * 8 + l] = ti < ns[s] ? tp[ns[s] + ti] : 0.0; }
       }
       tp += 2 * ns[s];
-      for (int i = l; i <= cap[s]; i += NL) L.ring[s][i] = 0.0;
+      for (int i = l; i <= ridx(cap[s]); i += NL) L.ring[s][i] = 0.0;
     }
     if (l < 8) { L.bc[l] = 0.0; L.pv[l] = 0.0; }
     sa_stage_tables(L.libm, l, NL);
@@ -164,6 +243,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     for (int tt = 0; tt < tend; tt++) {
       const int par = tt & 1;
       // ---- A: fused sweep (update of previous step, predict of this step)
+      if constexpr (!CANON) {
       ex.par([&](int l) {
         for (int s = 0; s < 4; s++) {
           const int f = C::first(s);
@@ -214,6 +294,112 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           dst[0] = acc[l].v[0]; dst[1] = acc[l].v[1];
         }
       });
+      } else {
+      // Canonical order (slmath::dot / calc_s2pow): weight update of this lane's chain positions, then the
+      // running sums hop along the lanes of each chain.  After hop h the sum held by lane m <= h is final, so
+      // after H = ceil(K / J) hops lane H-1 holds the chain total.
+      int Hd[4], Hp[4], Hmax = 0;
+      for (int s = 0; s < 4; s++) {
+        const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0, K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
+        Hd[s] = (K8 + C::slots(s) - 1) / C::slots(s);
+        Hp[s] = (K4 + C::slots(s) * SMUL - 1) / (C::slots(s) * SMUL);
+        Hmax = Hd[s] > Hmax ? Hd[s] : Hmax; Hmax = Hp[s] > Hmax ? Hp[s] : Hmax;
+      }
+      // power sums first, then the weight update + dot chains: the two phases reuse the same registers for
+      // their history values (both at once would overflow the 256-VGPR budget and spill inside the hop loops)
+      ex.par([&](int l) {
+        const int lw = l & 63, c4 = l >> 6;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int f = C::first(s);
+          const double *ring = L.ring[s];
+          const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
+          if (c4 < 4) {
+#pragma unroll
+            for (int j = 0; j < C::slots(s) * SMUL; j++) {
+              int tap = 4 * (lw * (C::slots(s) * SMUL) + j) + c4; tap = tap < last ? tap : last;
+              int in = ps + tap; if (in >= cp) in -= cp;
+              const double xs = ring[ridx(in)];
+              XX[l].v[f * SMUL + j] = xs * xs;
+            }
+          }
+          sq[s][l] = 0.0;
+        }
+      });
+      for (int h = 0; h < Hmax; h++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int f = C::first(s);
+          if (h < Hp[s]) {
+            hop = sq[s];
+            ex.shift_up1(hop);
+            ex.par([&](int l) {
+              double a = (l & 63) == 0 ? 0.0 : hop[l];
+#pragma unroll
+              for (int j = 0; j < C::slots(s) * SMUL; j++) a = fma(PT[l].v[f * SMUL + j], XX[l].v[f * SMUL + j], a);
+              sq[s][l] = a;
+            });
+          }
+        }
+      }
+      ex.par([&](int l) {
+        const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int f = C::first(s);
+          const double wg = L.bc[s];
+          const double *ring = L.ring[s];
+          const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
+          const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0;
+#pragma unroll
+          for (int j = 0; j < C::slots(s); j++) {
+            int tap = 8 * (m * C::slots(s) + j) + c; tap = tap < last ? tap : last;
+            int in = ps + tap; if (in >= cp) in -= cp;
+            const double xn = ring[ridx(in)], xo = ring[ridx(in + 1)];
+            double w = fma(MT[l].v[f + j], wg * xo, W[l].v[f + j]);
+            w = clampd(w, -10.0, 10.0);
+            W[l].v[f + j] = w;
+            XD[l].v[f + j] = xn;
+          }
+          {   // the chain's tail tap (lanes m == 0; elsewhere mutab is 0 and the weight stays 0)
+            int tap = 8 * K8 + c; tap = tap < last ? tap : last;
+            int in = ps + tap; if (in >= cp) in -= cp;
+            const double xo = ring[ridx(in + 1)];
+            double w = fma(MTt[l].v[s], wg * xo, Wt[l].v[s]);
+            w = clampd(w, -10.0, 10.0);
+            Wt[l].v[s] = w;
+            if (m == 0) L.tailw[(par * 4 + s) * 8 + c] = w;
+          }
+          sd[s][l] = 0.0;
+        }
+      });
+      SA_TICK(0);
+      for (int h = 0; h < Hmax; h++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int f = C::first(s);
+          if (h < Hd[s]) {
+            hop = sd[s];
+            ex.shift_up1(hop);
+            ex.par([&](int l) {
+              double a = ((l & 63) % LPC) == 0 ? 0.0 : hop[l];
+#pragma unroll
+              for (int j = 0; j < C::slots(s); j++) a = fma(XD[l].v[f + j], W[l].v[f + j], a);
+              sd[s][l] = a;
+            });
+          }
+        }
+      }
+      SA_TICK(1);
+      ex.par([&](int l) {
+        const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC, c4 = l >> 6;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          if (Hd[s] > 0 && m == Hd[s] - 1) L.csum[(par * 4 + s) * 8 + c] = sd[s][l];
+          if (Hp[s] > 0 && c4 < 4 && lw == Hp[s] - 1) L.psum[(par * 4 + s) * 4 + c4] = sq[s][l];
+        }
+      });
+      }
       ex.sync();
       SA_TICK(2);
       // ---- B: mixer chain.  Wave 0 turns the stage sums into the prediction (head), then into the
@@ -246,8 +432,30 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       ex.wave_par(0, [&](int l) {
         if (l >= 16 && l < 20) {   // cross-wave totals of stage l-16, waves in order (lanes 16..19 own the stage gains)
           const int s = l - 16;
-          double a = L.part[(par * NW) * 8 + s], b = L.part[(par * NW) * 8 + 4 + s];
-          for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + s]; b = b + L.part[(par * NW + w) * 8 + 4 + s]; }
+          double a, b;
+          if constexpr (!CANON) {
+            a = L.part[(par * NW) * 8 + s]; b = L.part[(par * NW) * 8 + 4 + s];
+            for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + s]; b = b + L.part[(par * NW + w) * 8 + 4 + s]; }
+          } else {
+            // slmath::dot: sum1 + sum2 lane-wise, ((b0+b1)+b2)+b3, += transform_reduce tail; calc_s2pow alike
+            const int nsl = s == 0 ? ns[0] : (s == 1 ? ns[1] : (s == 2 ? ns[2] : ns[3]));
+            const int cs = s == 0 ? cap[0] : (s == 1 ? cap[1] : (s == 2 ? cap[2] : cap[3]));
+            const int ps = s == 0 ? pos[0] : (s == 1 ? pos[1] : (s == 2 ? pos[2] : pos[3]));
+            const double *rg = s == 0 ? L.ring[0] : (s == 1 ? L.ring[1] : (s == 2 ? L.ring[2] : L.ring[3]));
+            const int K8 = nsl >= 8 ? nsl >> 3 : 0, K4 = nsl >= 8 ? nsl >> 2 : 0;
+            a = 0.0; b = 0.0;
+            if (K8 > 0) {
+              const double *q = L.csum + (par * 4 + s) * 8;
+              const double q0 = q[0] + q[4], q1 = q[1] + q[5], q2 = q[2] + q[6], q3 = q[3] + q[7];
+              a = ((q0 + q1) + q2) + q3;
+              const double *r = L.psum + (par * 4 + s) * 4;
+              b = ((r[0] + r[1]) + r[2]) + r[3];
+            }
+            auto hist = [&](int tap) { int in = ps + tap; if (in >= cs) in -= cs; return rg[ridx(in)]; };
+            const double *tw = L.tailw + (par * 4 + s) * 8, *tpw = L.tailpw + s * 8;
+            a = a + tr_dot_g(nsl - 8 * K8, [&](int u) { return hist(8 * K8 + u); }, [&](int u) { return tw[u]; });
+            b = b + tr_s2pow_g(nsl - 4 * K4, [&](int u) { return hist(4 * K4 + u); }, [&](int u) { return tpw[u]; });
+          }
           dots_r[l] = a; spow_r[l] = b; L.pv[s] = a;
         }
       });
@@ -359,8 +567,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           double *rg = sl == 0 ? L.ring[0] : (sl == 1 ? L.ring[1] : (sl == 2 ? L.ring[2] : L.ring[3]));
           L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
           int np = ps - 1; if (np < 0) np += cs;
-          rg[np] = bps;
-          if (np == 0) rg[cs] = bps;        // mirror: ring[in + 1] needs no wrap in the sweep
+          rg[ridx(np)] = bps;
+          if (np == 0) rg[ridx(cs)] = bps;        // mirror: ring[in + 1] needs no wrap in the sweep
         }
       });
       SA_TICK(4);

@@ -36,3 +36,11 @@ def golden():
 
     path = os.path.join(ROOT, "tests", "golden", "ref_golden.npz")
     return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden_r2():
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", "ref_golden_r2.npz")
+    return np.load(path, allow_pickle=False)

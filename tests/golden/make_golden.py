@@ -34,6 +34,44 @@ def main_subframes():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def main_r2():
+    """tests/golden/ref_golden_r2.npz: canonical-order cascade traces for every layout class and the full-size
+    (882 000-sample) frame records of the headline configuration (record bytes as SHA-256 + length + profile)."""
+    import hashlib
+    from golden_cases import FULL_FRAMESIZE, fullsize_cases, trace_cases_r2
+    R = Checker("ref")
+    out = {}
+    P = R.profile()
+    for name, (raw, coefs, opt, start, n) in trace_cases_r2(P).items():
+        smp, stats = center_frame(raw)
+        pd, plpc, plms, err = R.predict_trace(smp, stats, coefs, start, n, opt)
+        out[f"trace/{name}/raw"] = raw.astype(np.int16)
+        out[f"trace/{name}/coefs"] = coefs
+        out[f"trace/{name}/plpc"] = plpc
+        out[f"trace/{name}/plms"] = plms
+        out[f"trace/{name}/err"] = err
+    for name, (raw, cfg) in fullsize_cases().items():
+        r = R.encode_frame(raw, cfg, FULL_FRAMESIZE)
+        out[f"full/{name}/raw_sha256"] = np.frombuffer(hashlib.sha256(raw.astype(np.int16).tobytes()).digest(), np.uint8)
+        out[f"full/{name}/record_sha256"] = np.frombuffer(hashlib.sha256(r["record"]).digest(), np.uint8)
+        out[f"full/{name}/record_len"] = np.array([len(r["record"])], np.int64)
+        out[f"full/{name}/profile"] = r["profile"]
+        print(name, len(r["record"]), "bytes")
+    # the headline configuration itself (100 evaluations) on frame 0 of bench.py's batch: search trace + record
+    from oracle_api import frame_cfg
+    name, (raw, _) = next(iter(fullsize_cases().items()))
+    r = R.encode_frame(raw, frame_cfg("high", num_threads=8), FULL_FRAMESIZE, trace=True)
+    out["full100/trace_cost"] = r["trace_cost"]
+    out["full100/trace_coefs"] = r["trace_coefs"]
+    out["full100/profile"] = r["profile"]
+    out["full100/record_sha256"] = np.frombuffer(hashlib.sha256(r["record"]).digest(), np.uint8)
+    out["full100/record_len"] = np.array([len(r["record"])], np.int64)
+    print("full100", len(r["record"]), "bytes")
+    path = os.path.join(HERE, "ref_golden_r2.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     R = Checker("ref")
     out = {}
@@ -113,5 +151,7 @@ def main():
 if __name__ == "__main__":
     if "--subframes" in sys.argv:
         main_subframes()
+    elif "--r2" in sys.argv:
+        main_r2()
     else:
         main()

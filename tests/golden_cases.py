@@ -59,6 +59,37 @@ def trace_cases(P):
     return c
 
 
+def trace_cases_r2(P):
+    """Round-2 predictor traces (final pass, k = 1): stage lengths that exercise every canonical-order cascade
+    layout (512-lane classes), the transform_reduce tails (n % 8, n % 4 != 0) and the n < 8 stages."""
+    c = {}
+
+    def prof(t0, t1=None):
+        g = P[:, 2].copy()
+        g[28], g[29], g[30], g[37] = t0
+        g[31], g[32], g[33], g[38] = t1 if t1 is not None else t0
+        return g
+    c["tr_m16_taps_k1_512"] = (synth_pcm(900, 1, 40, RATE), prof((3001, 1500, 901, 300)), 0, 0, 900)
+    c["tr_m16_taps_k1_max"] = (synth_pcm(600, 1, 41, RATE), prof((6007, 3003, 1703, 601)), 0, 0, 600)
+    c["tr_s16_taps_k1_tiny"] = (synth_pcm(1200, 2, 42, RATE), prof((256, 32, 5, 2), (263, 39, 7, 3)), 0, 0, 1200)
+    c["tr_s16_taps_k1_tails"] = (synth_pcm(1000, 2, 43, RATE), prof((1283, 257, 33, 6), (2301, 1279, 767, 255)), 0, 0, 1000)
+    return c
+
+
+FULL_RATE = 44100
+FULL_FRAMESIZE = 20 * FULL_RATE
+
+
+def fullsize_cases():
+    """name -> (raw PCM [2, 882000], FrameCfg): BASELINE configs[2] at the size the metric is quoted on (20 s stereo
+    44.1 kHz, --high --opt-cfg=dds,8 --opt-reset, search window 88 200 samples) with a reduced evaluation count so
+    that the CPU reference finishes in seconds per frame."""
+    c = {}
+    for i in range(2):
+        c[f"full_s16_high_dds8_{i}"] = (synth_pcm(20 * FULL_RATE, 2, 1000 + i, FULL_RATE), frame_cfg("high", num_threads=8, maxnfunc=9))
+    return c
+
+
 def subframe_cases():
     """name -> (pcm [nch,n] int32 raw, blocksamples, min_frame_length): material whose 3-"second"
     blocks alternate between dense and sparse (quantised) PCM, for Codec::Analyse / PushState."""

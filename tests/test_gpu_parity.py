@@ -6,7 +6,8 @@ bit-exact; fp64 intermediates within the tolerance written next to each assertio
 import numpy as np
 import pytest
 
-from golden_cases import FRAMESIZE, RATE, frame_cases, rand_profile, trace_cases
+from golden_cases import (FRAMESIZE, FULL_FRAMESIZE, RATE, frame_cases, fullsize_cases, rand_profile, trace_cases,
+                          trace_cases_r2)
 from oracle_api import center_frame, frame_cfg, ref_available
 from sac_amd.synth import synth_pcm
 
@@ -70,10 +71,61 @@ def test_predictor_stages_vs_golden(api, golden, name):
     # glibc's pow it is bit-identical to the reference's p_lpc.
     rl = golden[f"trace/{name}/plpc"]
     assert np.array_equal(plpc.view(np.uint64), rl.view(np.uint64)), np.abs(plpc - rl).max()
-    # stage 2 (cascade): N-term NLMS dots are reduced lane-then-tree instead of slmath::dot's
-    # AVX2 order: tolerance 1e-9 relative on p_lpc+p_lms (observed ~1e-13)
     ps = rl + golden[f"trace/{name}/plms"]
-    assert np.max(np.abs(psum - ps) / (np.abs(ps) + 1.0)) < 1e-9
+    if opt:
+        # stage 2 (cascade) of a SEARCH evaluation (k = optk): N-term NLMS dots are reduced lane-then-tree instead
+        # of slmath::dot's AVX2 order: tolerance 1e-9 relative on p_lpc+p_lms (observed ~1e-13)
+        assert np.max(np.abs(psum - ps) / (np.abs(ps) + 1.0)) < 1e-9
+    else:
+        # final pass (k = 1, the arithmetic the decoder repeats): slmath::dot / calc_s2pow order, zero tolerance
+        assert np.array_equal(psum.view(np.uint64), ps.view(np.uint64)), np.abs(psum - ps).max()
+
+
+@pytest.mark.parametrize("name", list(trace_cases_r2(np.zeros((58, 3), np.float32)).keys()))
+def test_canonical_cascade_layouts_vs_golden(api, golden_r2, name):
+    """Final pass in every canonical-order cascade layout (256 lanes, 512 lanes, profile maximum) and with every
+    kind of transform_reduce tail: p_lpc and p_lpc + p_lms bit-identical to the genuine reference's."""
+    raw = golden_r2[f"trace/{name}/raw"].astype(np.int32)
+    coefs = golden_r2[f"trace/{name}/coefs"]
+    nch, n = raw.shape
+    ctx = api.Context(nch, FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    ctx.analyse(api.make_cfg("normal"))
+    plpc, psum, err, pred = ctx.debug_predict(0, coefs, 0, n, 0)
+    ctx.close()
+    rl = golden_r2[f"trace/{name}/plpc"]
+    assert np.array_equal(plpc.view(np.uint64), rl.view(np.uint64))
+    ps = rl + golden_r2[f"trace/{name}/plms"]
+    assert np.array_equal(psum.view(np.uint64), ps.view(np.uint64)), np.abs(psum - ps).max()
+    assert np.array_equal(err, golden_r2[f"trace/{name}/err"])
+
+
+def test_full_size_frames_vs_reference_golden(api, orc, golden_r2):
+    """BASELINE configs[2] at the size the metric is quoted on: two stereo frames of 882 000 samples, --high
+    --opt-cfg=dds,8 --opt-reset (search window 88 200 samples, evaluation count reduced to 9), encoded in one
+    batch.  (a) the record equals the genuine reference's (SHA-256 + length + chosen profile of the golden
+    file, generated here by oracle/_ref via tests/golden/make_golden.py --r2); (b) the oracle decoder
+    returns the input.  Exercises ring wrap over 882 k steps, the coder at full stream length and the
+    canonical-order final pass at full size."""
+    import hashlib
+    cases = fullsize_cases()
+    names = list(cases.keys())
+    raws = [cases[k][0] for k in names]
+    for k, raw in zip(names, raws):     # the synthetic input itself is pinned (numpy RNG drift would show here)
+        assert hashlib.sha256(raw.astype(np.int16).tobytes()).digest() == golden_r2[f"full/{k}/raw_sha256"].tobytes()
+    cfg = cases[names[0]][1]
+    ctx = api.Context(2, FULL_FRAMESIZE, len(raws))
+    il = np.ascontiguousarray(np.concatenate([r.T for r in raws], axis=0).astype(np.int16))
+    n = raws[0].shape[1]
+    ctx.upload_s16(il, [i * n for i in range(len(raws))], [n] * len(raws), FULL_FRAMESIZE)
+    recs, prof = ctx.encode_frames(gpu_cfg(api, cfg))
+    ctx.close()
+    for i, k in enumerate(names):
+        dec, _ = orc.decode_frame(recs[i], 2, FULL_FRAMESIZE)
+        assert np.array_equal(dec, raws[i]), k
+        assert np.array_equal(prof[i], golden_r2[f"full/{k}/profile"]), k
+        assert len(recs[i]) == int(golden_r2[f"full/{k}/record_len"][0]), k
+        assert hashlib.sha256(recs[i]).digest() == golden_r2[f"full/{k}/record_sha256"].tobytes(), k
 
 
 @pytest.mark.parametrize("name", list(frame_cases().keys()))
@@ -425,3 +477,31 @@ def test_kept_ols_streams_are_exact(api, orc):
             want = ctx.evaluate(cfg, np.array([i % 2], np.int32), cand[None])[0]
             assert want == have[i]
     ctx.close()
+
+
+def test_headline_config_search_and_record_vs_reference(api, orc, golden_r2):
+    """The headline configuration itself on frame 0 of bench.py's batch: 20 s stereo 44.1 kHz, --high
+    --opt-cfg=dds,8 --opt-reset, 100 evaluations over the 88 200-sample window.  (a) sacamd_evaluate on the
+    reference's own 100 candidates returns the reference's costs (entropy of integer residuals: rtol 1e-12);
+    (b) the complete GPU encode picks the same profile and writes the same record (SHA-256) as the genuine
+    reference (golden generated by oracle/_ref, tests/golden/make_golden.py --r2); (c) the oracle decodes it."""
+    import hashlib
+    raw = next(iter(fullsize_cases().values()))[0]
+    cfg = api.make_cfg("high", num_threads=8, reset=1)
+    ctx = api.Context(2, FULL_FRAMESIZE, 1)
+    il = np.ascontiguousarray(raw.T.astype(np.int16))
+    ctx.upload_s16(il, [0], [raw.shape[1]], FULL_FRAMESIZE)
+    ctx.analyse(cfg)
+    want = golden_r2["full100/trace_cost"]
+    coefs = golden_r2["full100/trace_coefs"]
+    got = ctx.evaluate(cfg, np.zeros(len(want), np.int32), coefs)
+    bad = np.nonzero(~np.isclose(got, want, rtol=1e-12, atol=0))[0]
+    assert bad.size == 0, (bad[:8], got[bad[:8]], want[bad[:8]])
+    ctx.upload_s16(il, [0], [raw.shape[1]], FULL_FRAMESIZE)     # fresh staging: the search starts without memo
+    recs, prof = ctx.encode_frames(cfg)
+    ctx.close()
+    assert np.array_equal(prof[0], golden_r2["full100/profile"])
+    assert len(recs[0]) == int(golden_r2["full100/record_len"][0])
+    assert hashlib.sha256(recs[0]).digest() == golden_r2["full100/record_sha256"].tobytes()
+    dec, _ = orc.decode_frame(recs[0], 2, FULL_FRAMESIZE)
+    assert np.array_equal(dec, raw)

@@ -5,7 +5,7 @@ import zlib
 import numpy as np
 import pytest
 
-from golden_cases import FRAMESIZE, frame_cases, trace_cases
+from golden_cases import FRAMESIZE, frame_cases, trace_cases, trace_cases_r2
 from oracle_api import center_frame
 
 
@@ -33,6 +33,19 @@ def test_predictor_trace_bit_exact(orc, golden, name):
     # predict_frame (no trace) gives the same residuals
     err2, _ = orc.predict_frame(smp, stats, coefs, start, n, opt)
     assert np.array_equal(err2, err)
+
+
+@pytest.mark.parametrize("name", list(trace_cases_r2(np.zeros((58, 3), np.float32)).keys()))
+def test_predictor_trace_r2_bit_exact(orc, golden_r2, name):
+    """The oracle against the round-2 reference traces (long / tiny / ragged NLMS stages, k = 1)."""
+    raw = golden_r2[f"trace/{name}/raw"].astype(np.int32)
+    coefs = golden_r2[f"trace/{name}/coefs"]
+    smp, stats = center_frame(raw)
+    n = raw.shape[1]
+    pd, plpc, plms, err = orc.predict_trace(smp, stats, coefs, 0, n, 0)
+    assert np.array_equal(err, golden_r2[f"trace/{name}/err"])
+    assert np.array_equal(plpc.view(np.uint64), golden_r2[f"trace/{name}/plpc"].view(np.uint64))
+    assert np.array_equal(plms.view(np.uint64), golden_r2[f"trace/{name}/plms"].view(np.uint64))
 
 
 @pytest.mark.parametrize("name", list(frame_cases().keys()))
