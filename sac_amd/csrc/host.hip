@@ -377,13 +377,25 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       std::vector<LmsRingCap> suf(m);
       for (int i = m - 1; i >= 0; i--)
         for (int q = 0; q < 4; q++) suf[i].c[q] = std::max(items[v[i]].p.vn[q] + 1, i + 1 < m ? suf[i + 1].c[q] : 0);
-      auto fit = [&](int i) { return std::min(lms_max_wg_per_cu(k), (int)(160 * 1024 / lms_lds_bytes(k, suf[i]))); };
+      constexpr size_t kLdsPerCu = 160 * 1024;
+      auto fit = [&](int i) { return std::min(lms_max_wg_per_cu(k), (int)(kLdsPerCu / std::max<size_t>(lms_lds_bytes(k, suf[i]), 1))); };
+      // a launch's rings are sized for the per-stage maximum over ITS items; that must fit one CU's LDS (every item
+      // alone does, by its class), so a launch also ends where the next item would push the combined size over
       int first = 0;
+      LmsRingCap cur;
+      for (int q = 0; q < 4; q++) cur.c[q] = items[v[0]].p.vn[q] + 1;
       for (int i = 1; i <= m; i++) {
-        if (i == m || (fit(i) > fit(first) && i - first >= 64 && m - i >= 64)) {
-          lms_launches.push_back({k, g, base + first, i - first, suf[first]});
-          first = i;
+        bool cut = i == m;
+        LmsRingCap nxt = cur;
+        if (!cut) {
+          for (int q = 0; q < 4; q++) nxt.c[q] = std::max(cur.c[q], items[v[i]].p.vn[q] + 1);
+          cut = lms_lds_bytes(k, nxt) > kLdsPerCu || (fit(i) > fit(first) && i - first >= 64 && m - i >= 64);
         }
+        if (cut) {
+          lms_launches.push_back({k, g, base + first, i - first, cur});
+          first = i;
+          if (i < m) for (int q = 0; q < 4; q++) cur.c[q] = items[v[i]].p.vn[q] + 1;
+        } else cur = nxt;
       }
     }
   HIPCHK(c, c->d_idx.ensure(flat.size() + 16));

@@ -119,6 +119,8 @@ using LmsY = LmsClass<13, 5, 3, 1>;
 // ring reads); 7: (2304, 1280, 768, 256) taps on 256 lanes, 8: twice that on 512 lanes, 9: the profile maximum
 using LmsK = LmsClass<9, 5, 3, 1>;
 using LmsL = LmsClass<17, 9, 5, 3>;
+// 7, 8: tables in LDS; 9: tables read from global memory (the fallback for anything that does not fit 7 / 8)
+constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : (cls == 9 ? 2 : 1); }
 template <int CLS> struct LmsCfg;
 template <> struct LmsCfg<0> { using C = LmsA; static constexpr int NL = 256, MINB = 1; };
 template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MINB = 2; };
@@ -137,12 +139,12 @@ __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(cons
   constexpr int NL = LmsCfg<CLS>::NL;
   using C = typename LmsCfg<CLS>::C;
   const WorkItem &it = items[idx[blockIdx.x]];
-  const ChanParam p = it.p;
+  const ChanParam &p = it.p;   // read through the scalar cache (uniform address); a private copy would live in scratch
   double sp[4];
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  lms_stage<ExecDev<NL>, C, (CLS >= kLmsCanonFirst)>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof);
+  lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS)>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof);
 }
 
 template <int CLS>
@@ -150,8 +152,10 @@ static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_id
   constexpr int NL = LmsCfg<CLS>::NL;
   using C = typename LmsCfg<CLS>::C;
   static std::atomic<unsigned long long> done{0};
-  constexpr bool CANON = CLS >= kLmsCanonFirst;
-  if (ensure_dyn_lds((const void *)k_lms<CLS>, LmsLds<NL, C, CANON>::bytes(), done) != hipSuccess) return;
+  constexpr int CANON = lms_canon_mode(CLS);
+  constexpr size_t kLdsPerCu = 160 * 1024;     // a layout's register capacity may exceed what one CU's LDS can hold as history
+  const size_t full = LmsLds<NL, C, CANON>::bytes();
+  if (ensure_dyn_lds((const void *)k_lms<CLS>, full < kLdsPerCu ? full : kLdsPerCu, done) != hipSuccess) return;
   const size_t bytes = LmsLds<NL, C, CANON>::bytes(rc.c);
   hipLaunchKernelGGL((k_lms<CLS>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_tab, d_p, d_q, rc);
 }
@@ -164,9 +168,9 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 4: return LmsLds<256, LmsE>::bytes(rc.c);
     case 5: return LmsLds<256, LmsX>::bytes(rc.c);
     case 6: return LmsLds<256, LmsY>::bytes(rc.c);
-    case 7: return LmsLds<256, LmsK, true>::bytes(rc.c);
-    case 8: return LmsLds<512, LmsK, true>::bytes(rc.c);
-    case 9: return LmsLds<512, LmsL, true>::bytes(rc.c);
+    case 7: return LmsLds<256, LmsK, 1>::bytes(rc.c);
+    case 8: return LmsLds<512, LmsK, 1>::bytes(rc.c);
+    case 9: return LmsLds<512, LmsL, 2>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
   }
 }
@@ -175,8 +179,10 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
 int lms_class_for(const int *vn, bool canon) {
   auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
   if (canon) {
-    if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 7;
-    if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 8;
+    // 7 / 8 keep mutab and powtab in LDS beside the histories (27 bytes per tap): they must fit one CU's LDS
+    LmsRingCap rc; for (int q = 0; q < 4; q++) rc.c[q] = vn[q] + 1;
+    if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3) && LmsLds<256, LmsK, 1>::bytes(rc.c) <= 160 * 1024) return 7;
+    if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3) && LmsLds<512, LmsK, 1>::bytes(rc.c) <= 160 * 1024) return 8;
     return 9;
   }
   if (fits(256, LmsA::c0, LmsA::c1, LmsA::c2, LmsA::c3)) return 0;

@@ -26,6 +26,7 @@
 //     floor any implementation of that summation order has.  The history rings are padded by one
 //     element per eight so that the strided reads are bank-conflict free for odd J.
 #pragma once
+#include <type_traits>
 #include "canon.h"
 #include "libm_port.h"
 #include "params.h"
@@ -57,10 +58,13 @@ SA_HD double dot_canon_m(int m, A a, B b) {
   }
 }
 
-template <int NL, class C, bool CANON = false>
+// CANON: 0 = free summation order (search), 1 = slmath::dot order with mutab / powtab in LDS, 2 = the same with the
+// tables read from global memory (profiles whose tables do not fit the CU's LDS beside the histories)
+template <int NL, class C, int CANON = 0>
 struct LmsLds {
   SA_HD static constexpr int ridx(int a) { return CANON ? a + (a >> 3) : a; }   // physical ring index
   double *csum, *psum, *tailw, *tailpw;   // CANON: chain sums [2][4][8], [2][4][4]; tail weights [2][4][8]; tail powtab [4][8]
+  double *mt[4], *pt[4];                  // CANON: mutab / powtab of each stage, indexed like the rings (ridx(tap)); read once per sample
   double *ring[4];
   double *part;     // [2][NL/64][8]
   double *bc;       // [8]: wgrad[4], unused
@@ -77,7 +81,8 @@ struct LmsLds {
   // footprint follows the taps actually in use, not the register-capacity class
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
-    for (int s = 0; s < 4; s++) d += (size_t)ridx(ringcap[s]) + 1;      // + the mirror element ring[cap] == ring[0]
+    #pragma unroll
+    for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringcap[s]) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
     if (CANON) d += 64 + 32 + 64 + 32;
     d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + NL * sizeof(int) + 16;
@@ -88,9 +93,16 @@ struct LmsLds {
   }
   SA_HD void carve(char *base, const int *ringcap) {
     double *d = reinterpret_cast<double *>(base);
-    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ridx(ringcap[s]) + 1; }
     csum = psum = tailw = tailpw = nullptr;
-    if (CANON) { csum = d; d += 64; psum = d; d += 32; tailw = d; d += 64; tailpw = d; d += 32; }
+    if (CANON) {
+      // the chain-sum arrays come first: ring[0] must not sit at LDS offset 0 (an address formed as "element
+      // i-1, immediate offset +8" would fall below the LDS aperture for i == 0 where the compiler uses a FLAT access)
+      csum = d; d += 64; psum = d; d += 32; tailw = d; d += 64; tailpw = d; d += 32;
+    }
+    #pragma unroll
+    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ridx(ringcap[s]) + 1; }
+    #pragma unroll
+    for (int s = 0; s < 4; s++) { mt[s] = pt[s] = nullptr; if (CANON == 1) { mt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; pt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; } }
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 8;
     pin = d; d += NL; pout = d; d += NL;
@@ -135,7 +147,7 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
   return init;
 }
 
-template <class E, class C, bool CANON = false>
+template <class E, class C, int CANON = 0>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
                      const int *self, int n, const double *pin_g, double *pout_g, char *lds_base, const int *ringcap,
                      unsigned long long *prof = nullptr) {
@@ -149,17 +161,20 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // run on waves 0..3, 64 lanes each, with SMUL times the slots per lane
   static_assert(!CANON || NL == 256 || NL == 512, "canonical layout: 4 or 8 waves");
   constexpr int CPW = CANON ? 8 / NW : 1, LPC = 64 / CPW, SMUL = CANON ? NL / 256 : 1;
-  constexpr int NX = CANON ? C::total : 1;
+  constexpr int NX = CANON ? C::slots(0) : 1;      // chain operands of ONE stage at a time; stage 0 has the most slots
+  static_assert(!CANON || (C::c0 >= C::c1 && C::c0 >= C::c2 && C::c0 >= C::c3), "stage 0 holds the most slots");
 
-  typename E::template Reg<DArr<C::total>> W, MT;
-  typename E::template Reg<DArr<C::total * SMUL>> PT;
+  typename E::template Reg<DArr<C::total>> W;
+  typename E::template Reg<DArr<CANON ? 1 : C::total>> MT, PT;   // CANON: the tables stay in LDS (read once per sample): the chain operands need the registers
+  typename E::template Reg<DArr<NX * SMUL>> PR;                 // CANON: powtab of this lane's power-chain taps, loaded for the duration of the chains
   typename E::template Reg<DArr<8>> acc;
-  typename E::template Reg<DArr<CANON ? 4 : 1>> Wt, MTt;        // CANON: the chain's tail tap (taps beyond 8*floor(n/8)) of lanes m == 0
+  typename E::template Reg<DArr<CANON ? 4 : 1>> Wt;        // CANON: the chain's tail tap (taps beyond 8*floor(n/8)) of lanes m == 0
   typename E::template Reg<DArr<NX>> XD;                        // CANON: history values of this lane's dot-chain taps
   typename E::template Reg<DArr<NX * SMUL>> XX;                 // CANON: squared history values of this lane's power-chain taps
   typename E::template Reg<double> sd[4], sq[4], hop;           // CANON: running chain sums
 
   int ns[4], cap[4], pos[4];
+  #pragma unroll
   for (int s = 0; s < 4; s++) { ns[s] = p.vn[s]; cap[s] = ns[s] + 1; pos[s] = 0; }
   const int m = p.lm_n;
 
@@ -176,6 +191,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   auto &exz_r = mr0;                                                        // wave 3
   ex.par([&](int l) {
     const double *tp = tab;
+    #pragma unroll
     for (int s = 0; s < 4; s++) {
       const int f = C::first(s);
       if constexpr (!CANON) {
@@ -189,22 +205,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       } else {
         // dot layout: lane (wave w, half, m) owns positions m*J..m*J+J-1 of chain c = w*CPW + half, i.e. taps 8k + c;
         // positions >= K8 = n/8 are empty.  The chain's tail tap 8*K8 + c (if < n) sits in the extra slot of lane m == 0.
-        const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
-        const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0, K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
-        for (int j = 0; j < C::slots(s); j++) {
-          const int k = m * C::slots(s) + j;
-          W[l].v[f + j] = 0.0;
-          MT[l].v[f + j] = k < K8 ? tp[8 * k + c] : 0.0;
-        }
-        const int tt = 8 * K8 + c;
+        const int K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
+        for (int j = 0; j < C::slots(s); j++) W[l].v[f + j] = 0.0;
         Wt[l].v[s] = 0.0;
-        MTt[l].v[s] = (m == 0 && tt < ns[s]) ? tp[tt] : 0.0;
-        // power-sum layout: lane m4 of wave c4 < 4 owns positions m4*JS.. of chain c4, taps 4k + c4, K4 = n/4 positions
-        const int c4 = l >> 6;
-        for (int j = 0; j < C::slots(s) * SMUL; j++) {
-          const int k = lw * (C::slots(s) * SMUL) + j;
-          PT[l].v[f * SMUL + j] = (c4 < 4 && k < K4) ? tp[ns[s] + 4 * k + c4] : 0.0;
-        }
+        if constexpr (CANON == 1) for (int i = l; i < ns[s]; i += NL) { L.mt[s][ridx(i)] = tp[i]; L.pt[s][ridx(i)] = tp[ns[s] + i]; }
         if (l < 8) { const int ti = 4 * K4 + l; L.tailpw[s * 8 + l] = ti < ns[s] ? tp[ns[s] + ti] : 0.0; }
       }
       tp += 2 * ns[s];
@@ -223,6 +227,9 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   });
   ex.sync();
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
+  const double *tg[4] = {tab, tab + 2 * ns[0], tab + 2 * (ns[0] + ns[1]), tab + 2 * (ns[0] + ns[1] + ns[2])};   // per-stage {mutab, powtab} in global memory
+  // ring s starts ro1 + .. + ro_s doubles after ring[0]
+  const int ro1 = (int)(L.ring[1] - L.ring[0]), ro2 = (int)(L.ring[2] - L.ring[1]), ro3 = (int)(L.ring[3] - L.ring[2]);
   // uniform mixer state (wave 0)
   double smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0, denom = 0.0, inv_alpha = 0.0, phi = 0.0;   // wave 3 / wave 2 uniform state
   bool have_prev = false;
@@ -245,6 +252,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       // ---- A: fused sweep (update of previous step, predict of this step)
       if constexpr (!CANON) {
       ex.par([&](int l) {
+        #pragma unroll
         for (int s = 0; s < 4; s++) {
           const int f = C::first(s);
           const double wg = L.bc[s];
@@ -298,98 +306,95 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       // Canonical order (slmath::dot / calc_s2pow): weight update of this lane's chain positions, then the
       // running sums hop along the lanes of each chain.  After hop h the sum held by lane m <= h is final, so
       // after H = ceil(K / J) hops lane H-1 holds the chain total.
-      int Hd[4], Hp[4], Hmax = 0;
+      int Hd[4], Hp[4];
+#pragma unroll
       for (int s = 0; s < 4; s++) {
         const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0, K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
         Hd[s] = (K8 + C::slots(s) - 1) / C::slots(s);
         Hp[s] = (K4 + C::slots(s) * SMUL - 1) / (C::slots(s) * SMUL);
-        Hmax = Hd[s] > Hmax ? Hd[s] : Hmax; Hmax = Hp[s] > Hmax ? Hp[s] : Hmax;
       }
-      // power sums first, then the weight update + dot chains: the two phases reuse the same registers for
-      // their history values (both at once would overflow the 256-VGPR budget and spill inside the hop loops)
-      ex.par([&](int l) {
-        const int lw = l & 63, c4 = l >> 6;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int f = C::first(s);
-          const double *ring = L.ring[s];
-          const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
+      // Stage by stage: power-sum chains (history squares + powtab in registers), then weight update and dot chains
+      // (history values in registers).  Only one stage's chain operands are live at a time, and the loops between
+      // the phases keep the compiler from hoisting every LDS load of the sample to the top (which spilled).
+      // One tight loop per chain set, four hops per iteration: a taken branch costs about as much as four
+      // dependent FMAs, and hops beyond H change nothing (the sum of lane m is final from hop m on).
+      auto canon_stage = [&](auto SC) {
+        constexpr int s = decltype(SC)::value;     // compile-time stage index: every register array below is indexed statically
+        constexpr int f = C::first(s);
+        const double *ring = L.ring[s];
+        const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
+        const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0, K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
+        ex.par([&](int l) {
+          const int lw = l & 63, c4 = l >> 6;
           if (c4 < 4) {
 #pragma unroll
             for (int j = 0; j < C::slots(s) * SMUL; j++) {
               int tap = 4 * (lw * (C::slots(s) * SMUL) + j) + c4; tap = tap < last ? tap : last;
               int in = ps + tap; if (in >= cp) in -= cp;
               const double xs = ring[ridx(in)];
-              XX[l].v[f * SMUL + j] = xs * xs;
+              XX[l].v[j] = xs * xs;
+              const double pw = CANON == 2 ? tg[s][ns[s] + tap] : L.pt[s][ridx(tap)];                                     // positions >= K4 are empty
+              PR[l].v[j] = (lw * (C::slots(s) * SMUL) + j) < K4 ? pw : 0.0;
             }
           }
           sq[s][l] = 0.0;
-        }
-      });
-      for (int h = 0; h < Hmax; h++) {
+        });
+        for (int h = 0; h < Hp[s]; h += 4) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int f = C::first(s);
-          if (h < Hp[s]) {
+          for (int u = 0; u < 4; u++) {
             hop = sq[s];
             ex.shift_up1(hop);
             ex.par([&](int l) {
               double a = (l & 63) == 0 ? 0.0 : hop[l];
 #pragma unroll
-              for (int j = 0; j < C::slots(s) * SMUL; j++) a = fma(PT[l].v[f * SMUL + j], XX[l].v[f * SMUL + j], a);
+              for (int j = 0; j < C::slots(s) * SMUL; j++) a = fma(PR[l].v[j], XX[l].v[j], a);
               sq[s][l] = a;
             });
           }
         }
-      }
-      ex.par([&](int l) {
-        const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int f = C::first(s);
+        ex.par([&](int l) {
+          const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
           const double wg = L.bc[s];
-          const double *ring = L.ring[s];
-          const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
-          const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0;
 #pragma unroll
           for (int j = 0; j < C::slots(s); j++) {
             int tap = 8 * (m * C::slots(s) + j) + c; tap = tap < last ? tap : last;
             int in = ps + tap; if (in >= cp) in -= cp;
             const double xn = ring[ridx(in)], xo = ring[ridx(in + 1)];
-            double w = fma(MT[l].v[f + j], wg * xo, W[l].v[f + j]);
+            const double mu_t = (m * C::slots(s) + j) < K8 ? (CANON == 2 ? tg[s][tap] : L.mt[s][ridx(tap)]) : 0.0;   // positions >= K8 are empty: the weight stays 0
+            double w = fma(mu_t, wg * xo, W[l].v[f + j]);
             w = clampd(w, -10.0, 10.0);
             W[l].v[f + j] = w;
-            XD[l].v[f + j] = xn;
+            XD[l].v[j] = xn;
           }
           {   // the chain's tail tap (lanes m == 0; elsewhere mutab is 0 and the weight stays 0)
             int tap = 8 * K8 + c; tap = tap < last ? tap : last;
             int in = ps + tap; if (in >= cp) in -= cp;
             const double xo = ring[ridx(in + 1)];
-            double w = fma(MTt[l].v[s], wg * xo, Wt[l].v[s]);
+            const double mu_t = (m == 0 && 8 * K8 + c < ns[s]) ? (CANON == 2 ? tg[s][tap] : L.mt[s][ridx(tap)]) : 0.0;
+            double w = fma(mu_t, wg * xo, Wt[l].v[s]);
             w = clampd(w, -10.0, 10.0);
             Wt[l].v[s] = w;
             if (m == 0) L.tailw[(par * 4 + s) * 8 + c] = w;
           }
           sd[s][l] = 0.0;
-        }
-      });
-      SA_TICK(0);
-      for (int h = 0; h < Hmax; h++) {
+        });
+        for (int h = 0; h < Hd[s]; h += 4) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int f = C::first(s);
-          if (h < Hd[s]) {
+          for (int u = 0; u < 4; u++) {
             hop = sd[s];
             ex.shift_up1(hop);
             ex.par([&](int l) {
               double a = ((l & 63) % LPC) == 0 ? 0.0 : hop[l];
 #pragma unroll
-              for (int j = 0; j < C::slots(s); j++) a = fma(XD[l].v[f + j], W[l].v[f + j], a);
+              for (int j = 0; j < C::slots(s); j++) a = fma(XD[l].v[j], W[l].v[f + j], a);
               sd[s][l] = a;
             });
           }
         }
-      }
+      };
+      canon_stage(std::integral_constant<int, 0>{}); canon_stage(std::integral_constant<int, 1>{});
+      canon_stage(std::integral_constant<int, 2>{}); canon_stage(std::integral_constant<int, 3>{});
+      SA_TICK(0);
       SA_TICK(1);
       ex.par([&](int l) {
         const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC, c4 = l >> 6;
@@ -437,24 +442,59 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
             a = L.part[(par * NW) * 8 + s]; b = L.part[(par * NW) * 8 + 4 + s];
             for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + s]; b = b + L.part[(par * NW + w) * 8 + 4 + s]; }
           } else {
-            // slmath::dot: sum1 + sum2 lane-wise, ((b0+b1)+b2)+b3, += transform_reduce tail; calc_s2pow alike
+            // slmath::dot: sum1 + sum2 lane-wise, ((b0+b1)+b2)+b3, += transform_reduce tail; calc_s2pow alike.
+            // The rings are addressed as offsets from ring[0] (one LDS base, no pointer select) and every load of
+            // the tails is issued before the arithmetic.
             const int nsl = s == 0 ? ns[0] : (s == 1 ? ns[1] : (s == 2 ? ns[2] : ns[3]));
             const int cs = s == 0 ? cap[0] : (s == 1 ? cap[1] : (s == 2 ? cap[2] : cap[3]));
             const int ps = s == 0 ? pos[0] : (s == 1 ? pos[1] : (s == 2 ? pos[2] : pos[3]));
-            const double *rg = s == 0 ? L.ring[0] : (s == 1 ? L.ring[1] : (s == 2 ? L.ring[2] : L.ring[3]));
+            const int ro = (s >= 1 ? ro1 : 0) + (s >= 2 ? ro2 : 0) + (s >= 3 ? ro3 : 0);   // sums, not a select among captured variables (which would pin the closure, and everything it references, in scratch)
+            const double *r0 = L.ring[0];
             const int K8 = nsl >= 8 ? nsl >> 3 : 0, K4 = nsl >= 8 ? nsl >> 2 : 0;
+            const int r8 = nsl - 8 * K8, r4 = nsl - 4 * K4, last = nsl - 1;
+            auto hist = [&](int tap) { tap = tap < last ? tap : last; int in = ps + tap; if (in >= cs) in -= cs; return r0[ro + ridx(in)]; };
+            const double *tw = L.tailw + (par * 4 + s) * 8, *tpw = L.tailpw + s * 8;
+            double xt[7], wt[7], xp[7], pt[7], q[8], r[4];
+#pragma unroll
+            for (int u = 0; u < 7; u++) { xt[u] = hist(8 * K8 + u); wt[u] = tw[u]; xp[u] = hist(4 * K4 + u); pt[u] = tpw[u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[u] = L.csum[(par * 4 + s) * 8 + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = L.psum[(par * 4 + s) * 4 + u];
             a = 0.0; b = 0.0;
             if (K8 > 0) {
-              const double *q = L.csum + (par * 4 + s) * 8;
               const double q0 = q[0] + q[4], q1 = q[1] + q[5], q2 = q[2] + q[6], q3 = q[3] + q[7];
               a = ((q0 + q1) + q2) + q3;
-              const double *r = L.psum + (par * 4 + s) * 4;
               b = ((r[0] + r[1]) + r[2]) + r[3];
             }
-            auto hist = [&](int tap) { int in = ps + tap; if (in >= cs) in -= cs; return rg[ridx(in)]; };
-            const double *tw = L.tailw + (par * 4 + s) * 8, *tpw = L.tailpw + s * 8;
-            a = a + tr_dot_g(nsl - 8 * K8, [&](int u) { return hist(8 * K8 + u); }, [&](int u) { return tw[u]; });
-            b = b + tr_s2pow_g(nsl - 4 * K4, [&](int u) { return hist(4 * K4 + u); }, [&](int u) { return tpw[u]; });
+            {   // transform_reduce tails (canon.h tr_dot / tr_s2pow) on register operands, selects instead of branches
+              const bool g4 = r8 >= 4;
+              const double v1 = fma(xt[1], wt[1], xt[0] * wt[0]), v2 = fma(xt[3], wt[3], xt[2] * wt[2]);
+              double init = g4 ? 0.0 + (v1 + v2) : 0.0;
+              const int rem = g4 ? r8 - 4 : r8;
+              const double e0 = g4 ? xt[4] : xt[0], e1 = g4 ? xt[5] : xt[1], e2 = g4 ? xt[6] : xt[2];
+              const double f0 = g4 ? wt[4] : wt[0], f1 = g4 ? wt[5] : wt[1], f2 = g4 ? wt[6] : wt[2];
+              const double i2 = (init + e0 * f0) + e1 * f1;
+              init = rem >= 2 ? i2 : init;
+              const double el = rem >= 2 ? e2 : e0, fl = rem >= 2 ? f2 : f0;
+              const double i3 = fma(el, fl, init);
+              init = (rem & 1) ? i3 : init;
+              a = a + init;
+            }
+            {
+              const bool g4 = r4 >= 4;
+              const double v1 = fma(xp[1] * xp[1], pt[1], (xp[0] * xp[0]) * pt[0]), v2 = fma(xp[3] * xp[3], pt[3], (xp[2] * xp[2]) * pt[2]);
+              double init = g4 ? 0.0 + (v1 + v2) : 0.0;
+              const int rem = g4 ? r4 - 4 : r4;
+              const double e0 = g4 ? xp[4] : xp[0], e1 = g4 ? xp[5] : xp[1], e2 = g4 ? xp[6] : xp[2];
+              const double f0 = g4 ? pt[4] : pt[0], f1 = g4 ? pt[5] : pt[1], f2 = g4 ? pt[6] : pt[2];
+              const double i2 = (init + (e0 * e0) * f0) + (e1 * e1) * f1;
+              init = rem >= 2 ? i2 : init;
+              const double el = rem >= 2 ? e2 : e0, fl = rem >= 2 ? f2 : f0;
+              const double i3 = fma(el * el, fl, init);
+              init = (rem & 1) ? i3 : init;
+              b = b + init;
+            }
           }
           dots_r[l] = a; spow_r[l] = b; L.pv[s] = a;
         }
@@ -564,7 +604,9 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const double bps = sl == 0 ? bp[0] : (sl == 1 ? bp[1] : (sl == 2 ? bp[2] : bp[3]));
           const int ps = sl == 0 ? pos[0] : (sl == 1 ? pos[1] : (sl == 2 ? pos[2] : pos[3]));
           const int cs = sl == 0 ? cap[0] : (sl == 1 ? cap[1] : (sl == 2 ? cap[2] : cap[3]));
-          double *rg = sl == 0 ? L.ring[0] : (sl == 1 ? L.ring[1] : (sl == 2 ? L.ring[2] : L.ring[3]));
+          // one LDS base + offset: a select among the four ring pointers becomes a load through a selected ADDRESS
+          // inside the LmsLds object, which pins that object (and every pointer in it) in scratch memory
+          double *rg = L.ring[0] + ((sl >= 1 ? ro1 : 0) + (sl >= 2 ? ro2 : 0) + (sl >= 3 ? ro3 : 0));
           L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
           int np = ps - 1; if (np < 0) np += cs;
           rg[ridx(np)] = bps;
@@ -575,6 +617,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       ex.sync();
       SA_TICK(5);
       have_prev = true;
+      #pragma unroll
       for (int s = 0; s < 4; s++) { pos[s] -= 1; if (pos[s] < 0) pos[s] += cap[s]; }
       SA_TICK(6);
       SA_TICK(7);

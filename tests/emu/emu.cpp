@@ -14,9 +14,10 @@
 using namespace sacamd;
 #define API extern "C" __attribute__((visibility("default")))
 
-template <class C, int NL = 256, bool CANON = false>
+template <class C, int NL = 256, int CANON = 0>
 static void run_lms(const ChanParam &p, const double *sp, const double *tab, const int *self, int n, double *pio) {
-  std::vector<char> lds(LmsLds<NL, C, CANON>::bytes());
+  const int rc0[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};
+  std::vector<char> lds(LmsLds<NL, C, CANON>::bytes(rc0), (char)0xFF);   // tight, as the launcher sizes the dynamic LDS; LDS is not zeroed on the device: start from NaN bit patterns
   ExecEmu<NL> *ex = new ExecEmu<NL>;
   const int rc[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};   // tight rings, as the host sizes them
   lms_stage<ExecEmu<NL>, C, CANON>(*ex, p, sp, tab, self, n, pio, pio, lds.data(), rc);
@@ -61,9 +62,10 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     for (int t = 0; t < n; t++) ps[t] = pl[t];
     const int *vn = p.vn;
     if (!optimize) {   // as the launcher (lms_class_for): the final pass sums in slmath::dot order
-      if (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256) run_lms<LmsClass<9, 5, 3, 1>, 256, true>(p, sp, tab.data(), self, n, ps);
-      else if (vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) run_lms<LmsClass<9, 5, 3, 1>, 512, true>(p, sp, tab.data(), self, n, ps);
-      else run_lms<LmsClass<17, 9, 5, 3>, 512, true>(p, sp, tab.data(), self, n, ps);
+      const int rc[4] = {vn[0] + 1, vn[1] + 1, vn[2] + 1, vn[3] + 1};
+      if (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256 && LmsLds<256, LmsClass<9, 5, 3, 1>, 1>::bytes(rc) <= 160 * 1024) run_lms<LmsClass<9, 5, 3, 1>, 256, 1>(p, sp, tab.data(), self, n, ps);
+      else if (vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512 && LmsLds<512, LmsClass<9, 5, 3, 1>, 1>::bytes(rc) <= 160 * 1024) run_lms<LmsClass<9, 5, 3, 1>, 512, 1>(p, sp, tab.data(), self, n, ps);
+      else run_lms<LmsClass<17, 9, 5, 3>, 512, 2>(p, sp, tab.data(), self, n, ps);
     }
     else if (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) run_lms<LmsClass<8, 4, 2, 1>>(p, sp, tab.data(), self, n, ps);
     else if (vn[0] <= 1536 && vn[1] <= 2560 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<6, 10, 4, 2>>(p, sp, tab.data(), self, n, ps);
