@@ -174,9 +174,9 @@ def main():
     ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 384)), help="frames per GPU per step")
     ap.add_argument("--seconds", type=float, default=float(os.environ.get("SAC_BENCH_SECONDS", 20.0)), help="frame length")
     ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("SAC_BENCH_GROUPS", 1)),
-                    help="frame groups per GPU, each with its own context and HIP streams, software-pipelined: group g+1 "
-                         "starts its search when group g enters its latency-bound final pass + coder")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SAC_BENCH_PIPELINE", 1)),
+                    help="contexts per GPU over which consecutive steps are software-pipelined: step i+1's search runs "
+                         "under step i's latency-bound final pass + coder")
     ap.add_argument("--mode", default="high")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="decode every record of the last step with the oracle afterwards (slow)")
@@ -216,32 +216,31 @@ def main():
     cfg = api.make_cfg(args.mode, num_threads=args.dds_n, reset=1)
     # The kernels are latency-bound recurrences (one wave or one workgroup per frame x candidate x
     # channel).  A batch ends with a latency-bound tail (final pass: one work-item per frame x channel,
-    # then the range coder) that leaves most of the chip idle, so independent groups of frames, each with
-    # its own context (device buffers, HIP streams), are software-pipelined: while one group is in its
-    # tail the next group's search generations fill the chip.
-    ngroups = max(1, min(args.groups, args.frames))
-    bounds = [round(g * args.frames / ngroups) for g in range(ngroups + 1)]
-    groups = []
-    for g in range(ngroups):
-        lo, hi = bounds[g], bounds[g + 1]
-        ctx = api.Context(2, max(n, 16), hi - lo, device=local_rank)
-        groups.append((ctx, np.arange(lo, hi, dtype=np.int64) * n, np.full(hi - lo, n, np.int32)))
+    # then the range coder) that leaves most of the chip idle, so consecutive steps are software-pipelined
+    # over --pipeline contexts (each with its own device buffers): step i runs on context i % depth, and while
+    # one context is in its tail the next step's search fills the chip.  Every context stages the whole
+    # batch; the library lets one search run at a time per device and puts tails on high-priority streams.
+    depth = max(1, args.pipeline)
+    ctxs = [api.Context(2, max(n, 16), args.frames, device=local_rank) for _ in range(depth)]
+    frame_off = np.arange(args.frames, dtype=np.int64) * n
+    nsamp = np.full(args.frames, n, np.int32)
+    groups = [(c, frame_off, nsamp) for c in ctxs]     # (kept name: the statistics helpers below iterate over it)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_group(g, small=False):
-        ctx, frame_off, nsamp = groups[g]
-        if small:     # warm-up: first frames of the group, 2 s each
-            k = min(len(nsamp), 8)
+    def run_step(d, small=False):
+        ctx = ctxs[d]
+        if small:     # warm-up: first frames of the batch, 2 s each
+            k = min(args.frames, 8)
             ns = np.minimum(nsamp[:k], 2 * RATE).astype(np.int32)
             ctx.attach_s16_device(d_pcm.data_ptr(), frame_off[:k], ns, framesize)
         else:
             ctx.attach_s16_device(d_pcm.data_ptr(), frame_off, nsamp, framesize)
         ctx.analyse(cfg)
-        recs, prof = ctx.encode_frames(cfg)      # ctypes releases the GIL: groups overlap on the GPU
+        recs, prof = ctx.encode_frames(cfg)      # ctypes releases the GIL: the other contexts' steps overlap on the GPU
         return recs
 
     def class_times():
@@ -270,36 +269,43 @@ def main():
 
     # ---- warm-up on a reduced batch
     for _ in range(args.warmup):
-        for g in range(ngroups):
-            run_group(g, small=True)
+        for d in range(depth):
+            run_step(d, small=True)
     kernel_times(); class_times()
-    for ctx, _, _ in groups:
+    for ctx in ctxs:
         ctx.eval_stats(reset=True)
 
-    # ---- timed region: pipelined groups, steps decided against the wall budget
+    # ---- timed region: steps pipelined over the contexts, their number decided against the wall budget
     budget = args.budget_s if args.budget_s > 0 else float("inf")
     steps_max = max(1, args.steps)
     lock = threading.Condition()
-    state = {"decided": 1, "final": None, "done": [[None] * ngroups for _ in range(steps_max)], "error": None}
+    # planned: number of steps that will be run; the first `depth` are committed, the rest is decided (on all
+    # ranks alike) when step 0 has completed and its duration is known
+    state = {"planned": None, "done": [None] * steps_max, "started": [False] * steps_max, "error": None}
 
-    def worker(g):
+    def worker(d):
         try:
-            step = 0
-            while True:
+            for step in range(d, steps_max, depth):
                 with lock:
-                    while state["final"] is None and state["decided"] <= step:
+                    while step >= depth and state["planned"] is None and state["error"] is None:
                         lock.wait()
-                    if state["final"] is not None and step >= state["final"]:
+                    if state["error"] is not None or (state["planned"] is not None and step >= state["planned"]):
                         return
-                if g > 0 and step == 0:       # stagger: start when the previous group enters its final pass
-                    prev = groups[g - 1][0]
-                    while prev.progress()[0] < 2 and state["done"][0][g - 1] is None and state["error"] is None:
-                        time.sleep(0.02)
-                recs = run_group(g)
+                    # keep the steps in order: wait until the previous step has begun (its search holds the device's
+                    # search lock; this step's search then queues behind it)
+                    while step > 0 and not state["started"][step - 1] and state["error"] is None:
+                        lock.wait()
+                if step > 0:
+                    prev = ctxs[(step - 1) % depth]
+                    while prev.progress()[0] < 1 and state["done"][step - 1] is None and state["error"] is None:
+                        time.sleep(0.005)
                 with lock:
-                    state["done"][step][g] = (recs, time.perf_counter())
+                    state["started"][step] = True
                     lock.notify_all()
-                step += 1
+                recs = run_step(d)
+                with lock:
+                    state["done"][step] = (recs, time.perf_counter())
+                    lock.notify_all()
         except BaseException as e:       # surface worker failures in the main thread
             with lock:
                 state["error"] = e
@@ -326,7 +332,7 @@ def main():
             "config": {"workload": f"{args.frames} frames/GPU x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
                                    f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
                        "frames_per_gpu": args.frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
-                       "pipelined_groups": ngroups, "rccl_ranks": world,
+                       "pipeline_depth": depth, "rccl_ranks": world,
                        "parallelism": f"frames sharded over {world} GPU(s), RCCL record gather",
                        "warmup_batch": "min(8, frames of the group) frames x 2 s per group (code-object load only)",
                        "budget_s": args.budget_s},
@@ -341,7 +347,7 @@ def main():
 
     def add_kernel_report(out, nsteps):
         kt = kernel_times(); ct = class_times()
-        ev = [ctx.eval_stats() for ctx, _, _ in groups]
+        ev = [ctx.eval_stats() for ctx in ctxs]
 
         def kname(kind, cls):
             if kind == "ols":
@@ -383,52 +389,45 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker, args=(g,), daemon=True) for g in range(ngroups)]
+    threads = [threading.Thread(target=worker, args=(d,), daemon=True) for d in range(depth)]
     for t in threads:
         t.start()
     allrecs = last_recs = None
     nsteps = 0
-    dt = 0.0
-    for step in range(steps_max):
-        # group 0 finishes step `step` first: decide whether another step fits the budget
+    step = 0
+    while True:
         with lock:
-            while state["done"][step][0] is None and state["error"] is None:
+            while state["done"][step] is None and state["error"] is None:
                 lock.wait()
             if state["error"] is not None:
                 raise state["error"]
-        t_g0 = state["done"][step][0][1]
-        more = step + 1 < steps_max
-        if more:
-            per_step = (t_g0 - t0) / (step + 1)
-            tail = 0.6 * per_step if ngroups > 1 else 0.0          # the other groups still have to drain
-            est_end = (time.time() - t_start) + per_step * 1.08 + tail + 25.0
-            more = est_end < budget
-        if dist is not None:                 # all ranks take the same decision
-            flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            more = bool(flag.item())
-        with lock:
-            if more:
-                state["decided"] = step + 2
-            else:
-                state["final"] = step + 1
-            lock.notify_all()
-        with lock:
-            while any(d is None for d in state["done"][step]) and state["error"] is None:
-                lock.wait()
-            if state["error"] is not None:
-                raise state["error"]
-        recs = [r for part in state["done"][step] for r in part[0]]
-        state["done"][step] = [True] * ngroups      # drop the payloads
+        recs, t_done = state["done"][step]
+        state["done"][step] = (None, t_done)      # drop the payload
+        if step == 0:
+            # how many steps fit the budget: step 0 took t_first from start to end; in steady state a step costs
+            # about its search time (tails hidden) -- estimated at 70 % of t_first when pipelined
+            t_first = t_done - t0
+            per_step = t_first * (0.7 if depth > 1 else 1.0)
+            left = budget - (time.time() - t_start) - 25.0 - (t_first * 0.5 if depth > 1 else 0.0)
+            planned = 1 + max(0, int(left // (per_step * 1.05))) if budget != float("inf") else steps_max
+            planned = max(min(planned, steps_max), min(depth, steps_max))
+            if dist is not None:                 # all ranks plan the same number of steps
+                pl = torch.tensor([planned], dtype=torch.int32, device=device)
+                dist.all_reduce(pl, op=dist.ReduceOp.MIN)
+                planned = max(int(pl.item()), min(depth, steps_max))
+            with lock:
+                state["planned"] = planned
+                lock.notify_all()
         allrecs = gather_records(recs, rank, world, device) if dist is not None else recs
         last_recs = recs
         nsteps = step + 1
-        if not more:
+        if nsteps >= state["planned"]:
             break
         if rank == 0:        # cumulative line (the timed region is still open: no barrier here)
             dt_now = time.perf_counter() - t0
             latest["line"] = json.dumps(build_line(nsteps, dt_now, allrecs, last_recs, final=False))
             print(latest["line"], flush=True)
+        step += 1
     barrier()
     dt = time.perf_counter() - t0
     for t in threads:

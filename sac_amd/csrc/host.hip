@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <unistd.h>
 #include <numeric>
 #include <tuple>
 #include <random>
@@ -89,8 +91,14 @@ struct TraceSpan { char label[64]; int kind, cls; double item_steps, flops; hipE
 struct sacamd_ctx {
   int device = 0, nch = 0, max_framesize = 0, max_frames = 0;
   hipStream_t stream = nullptr;
-  static constexpr int kSide = 20;                 // side streams: 8 OLS classes + cascade launches (GPU_MAX_HW_QUEUES=24)
+  static constexpr int kSide = 13;                 // logical side streams: 8 OLS classes + 4 cascade launches + 1 marker
   hipStream_t cls_stream[kSide] = {};
+  // `stream` / `cls_stream` are the ACTIVE set, taken from the per-device pool (DevStreams below): lane 0 = the
+  // normal set shared by all contexts of the device, lane 1 = one of two high-priority sets that
+  // sacamd_encode_frames switches to for the latency-bound tail of a batch (final pass + coder)
+  int lane = 0;
+  hipStream_t own_main = nullptr;                  // this context's main stream of the normal set (the side streams are pooled)
+  int tail_hi = 0, tail_prio = 0;                  // SACAMD_TAIL_HI / SACAMD_TAIL_PRIO (default off): tail on the high-priority streams / with raised wave priority
   hipEvent_t ev_fork = nullptr, ev_join[kSide] = {}, ev_ols[kNumOlsClasses] = {};
   std::string err;
   unsigned long long *d_prof = nullptr;   // debug: OLS section counters
@@ -110,6 +118,8 @@ struct sacamd_ctx {
   DevBuf<unsigned char> d_used;
   // predictor scratch
   DevBuf<WorkItem> d_items;
+  DevBuf<int> d_progress;     // final pass: per work-item OLS progress + [count] = number of OLS workgroups begun (PcmView::progress / started)
+  int chase = 1;              // SACAMD_CHASE: run the final pass's cascade kernels concurrently with its OLS kernels
   DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist, d_nf;   // d_nf: per work-item "prediction not finite" flags of the last run_predict
   std::vector<int> h_nf;
   DevBuf<double> d_tab, d_p, d_q, d_cost;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
@@ -223,7 +233,72 @@ int sync_stream(sacamd_ctx *c) {
   return 0;
 }
 
-PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride, c->d_prof, c->d_olskeep.p}; }
+PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride, c->d_prof, c->d_olskeep.p, nullptr, nullptr, c->lane && c->tail_prio}; }
+
+// Streams are a per-DEVICE pool, shared by every context on the device and never destroyed.  The hardware runs a
+// limited number of queues at once (oversubscribing them makes the queue scheduler time-slice long kernels, which was
+// measured as an 11x slowdown with three contexts of 42 private streams each), so the pool holds 28 streams in all:
+//   normal set:  main + 8 (OLS capacity classes) + 4 (cascade launches) + 1 (marker)           = 14
+//   two high-priority sets (own hardware queues):  main + 3 (OLS) + 3 (cascade)                =  7 each
+// Contexts that keep several batches in flight (one host thread each) interleave their search generations on the
+// normal set -- they are throughput-bound and would share the chip anyway -- while the tails of two batches run on
+// the two high-priority sets.  Work of different contexts on one stream is ordered by that stream, which only ever
+// over-synchronises; every cross-stream dependency is an event owned by the context that recorded it.
+struct DevStreams {
+  bool ready = false;
+  hipStream_t lo_main = nullptr, lo_cls[sacamd_ctx::kSide] = {};
+  hipStream_t hi_main[2] = {}, hi_cls[2][6] = {};
+  std::atomic<unsigned> tails{0};
+  // One search at a time per device: a batch's search saturates the chip on its own, and two searches issued to the
+  // pooled streams would only queue behind each other's dependency chains.  What does overlap is the search of one
+  // context with the latency-bound TAIL of another (sacamd_encode_frames releases this before its tail).
+  std::mutex search_mu;
+};
+DevStreams g_streams[64];
+std::mutex g_streams_mu;
+
+int ensure_dev_streams(int device, bool want_hi) {
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DevStreams &d = g_streams[device & 63];
+  if (!d.ready) {
+    if (hipStreamCreate(&d.lo_main) != hipSuccess) return SACAMD_ERR_HIP;
+    for (int k = 0; k < sacamd_ctx::kSide; k++)
+      if (hipStreamCreate(&d.lo_cls[k]) != hipSuccess) return SACAMD_ERR_HIP;
+    d.ready = true;
+  }
+  // The two tail sets exist only on request (SACAMD_TAIL_HI=1) and have the DEFAULT priority unless
+  // SACAMD_POOL_PRIO=1.  Measured on MI355X: the mere existence of high-priority streams in the process slows EVERY
+  // kernel by 20-25 % (coder 3.05 -> 4.1 s, OLS 9.8 -> 13.1 s per step of the 64 x 4 s run), whichever stream it is on.
+  if (want_hi && !d.hi_main[0]) {
+    int prio_lo = 0, prio_hi = 0;
+    const char *e = std::getenv("SACAMD_POOL_PRIO");
+    if (!(e && e[0] == '1') || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { prio_lo = prio_hi = 0; }
+    for (int h = 0; h < 2; h++) {
+      if (hipStreamCreateWithPriority(&d.hi_main[h], hipStreamDefault, prio_hi) != hipSuccess) return SACAMD_ERR_HIP;
+      for (int k = 0; k < 6; k++)
+        if (hipStreamCreateWithPriority(&d.hi_cls[h][k], hipStreamDefault, prio_hi) != hipSuccess) return SACAMD_ERR_HIP;
+    }
+  }
+  return 0;
+}
+
+// make a stream set the active one: lane 0 = normal, lane 1 = the next high-priority set in rotation.  In a
+// high-priority set the logical slots alias 7 physical streams: the final pass only launches the promoted OLS classes
+// 2 / 5 / 6 / 7 (build_items) and the three canonical cascade classes.  The caller has synchronised the current set.
+void set_lane(sacamd_ctx *c, int lane) {
+  DevStreams &d = g_streams[c->device & 63];
+  c->lane = lane;
+  if (!lane) {
+    c->stream = c->own_main ? c->own_main : d.lo_main;
+    for (int k = 0; k < sacamd_ctx::kSide; k++) c->cls_stream[k] = d.lo_cls[k];
+    return;
+  }
+  const int h = (int)(d.tails.fetch_add(1) & 1);
+  c->stream = d.hi_main[h];
+  for (int k = 0; k < kNumOlsClasses; k++) c->cls_stream[k] = d.hi_cls[h][k <= 2 ? 0 : (k <= 5 ? 1 : 2)];
+  for (int q = 0; q < 4; q++) c->cls_stream[kNumOlsClasses + q] = d.hi_cls[h][3 + q % 3];
+  c->cls_stream[sacamd_ctx::kSide - 1] = d.hi_main[h];       // the marker only orders events
+}
 
 // ------------------------------------------------------------ work-item construction
 struct Cand { int frame; const float *coefs; int start, n; bool optimize; int optk; };
@@ -251,6 +326,10 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
         if (p.vn[s] < 1 || p.vn[s] > (8192 >> s)) return fail(c, SACAMD_ERR_ARG, "NLMS stage length outside the profile box");
       it.ols_class = 0;
       while (p.n_ols > kOlsClassMax[it.ols_class]) it.ols_class++;
+      // The final pass (latency-bound, one work-item per frame x channel) uses the capacity classes 32, 56, 64 and 96 taps
+      // only, so that its OLS kernels need three streams, not eight (see DevStreams; the 64 / 96-tap kernels hold one
+      // workgroup per CU and share a stream)
+      if (!cd.optimize && c->tail_hi) it.ols_class = it.ols_class <= 2 ? 2 : (it.ols_class <= 5 ? 5 : it.ols_class);
       const int *vn = p.vn;
       it.lms_class = lms_class_for(vn, /*canon=*/!cd.optimize);   // the final pass (k = 1, what the decoder recomputes) sums in slmath::dot order
       it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab;
@@ -272,6 +351,26 @@ double ols_flops(const WorkItem &it) {
 double lms_flops(const WorkItem &it) {
   const double taps = it.p.vn[0] + it.p.vn[1] + it.p.vn[2] + it.p.vn[3];
   return (double)it.n * (10 * taps + 200);
+}
+
+// Workgroup i of a launch runs on XCD i % 8, and every XCD has its own L2.  All work-items of one frame read the same
+// PCM, so the launch list is arranged such that a frame's items sit at list positions of ONE residue mod 8 (frame % 8)
+// and follow each other there: the frame's samples are fetched into one L2 instead of eight.  `v` is in launch order
+// (heaviest first); the order within each residue class is kept.  Classes are padded to equal length with -1 (the
+// kernels return at once for those).
+constexpr int kXcds = 8;
+std::vector<int> xcd_interleave(const std::vector<int> &v, const std::vector<WorkItem> &items) {
+  if ((int)v.size() < 4 * kXcds) return v;
+  std::vector<int> b[kXcds];
+  for (int i : v) b[items[i].frame % kXcds].push_back(i);
+  size_t len = 0;
+  for (auto &q : b) len = std::max(len, q.size());
+  std::vector<int> out;
+  out.reserve(len * kXcds);
+  for (size_t r = 0; r < len; r++)
+    for (int x = 0; x < kXcds; x++) out.push_back(r < b[x].size() ? b[x][r] : -1);
+  while (!out.empty() && out.back() < 0) out.pop_back();
+  return out;
 }
 
 // run the three predictor stages for `items`; residual -> d_err (+ d_pred when want_pred)
@@ -340,6 +439,17 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     }
   }
   for (int i = 0; i < count; i++) if (ols_lead[i] != i) { items[i].off_pin = items[ols_lead[i]].off_pin; items[i].pin_kept = items[ols_lead[i]].pin_kept; }
+  for (int i = 0; i < count; i++) items[i].ols_item = ols_lead[i];
+  // Final pass: the cascade of an item does not wait for the whole OLS launch -- it runs at the same time and follows
+  // its OLS stage chunk by chunk through a progress counter (both are latency-bound and sit on different SIMDs), so the
+  // pass costs max(OLS, cascade) instead of their sum.
+  const bool chase = want_pred && c->chase && !c->ols_keep_on;
+  PcmView pv = view(c);
+  if (chase) {
+    HIPCHK(c, c->d_progress.ensure((size_t)count + 1));
+    HIPCHK(c, hipMemsetAsync(c->d_progress.p, 0, sizeof(int) * ((size_t)count + 1), c->stream));
+    pv.progress = c->d_progress.p; pv.started = c->d_progress.p + count;
+  }
   if (want_pred) HIPCHK(c, c->d_pred.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
@@ -356,10 +466,14 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
   std::vector<int> flat;
-  int base_ols[kNumOlsClasses];
+  int base_ols[kNumOlsClasses], cnt_ols[kNumOlsClasses];
   for (int k = 0; k < kNumOlsClasses; k++) {
-    std::stable_sort(idx_ols[k].begin(), idx_ols[k].end(), [&](int a, int b) { return olsw(a) > olsw(b); });
-    base_ols[k] = (int)flat.size(); flat.insert(flat.end(), idx_ols[k].begin(), idx_ols[k].end());
+    // heaviest first; equal weights (same regressor length, window and k) grouped by frame
+    std::stable_sort(idx_ols[k].begin(), idx_ols[k].end(), [&](int a, int b) {
+      const long long wa = olsw(a), wb = olsw(b);
+      return wa != wb ? wa > wb : items[a].frame < items[b].frame; });
+    const std::vector<int> lst = xcd_interleave(idx_ols[k], items);
+    base_ols[k] = (int)flat.size(); cnt_ols[k] = (int)lst.size(); flat.insert(flat.end(), lst.begin(), lst.end());
   }
   // Cascade launches: the history rings are sized for the taps in use.  Each list (sorted by taps)
   // is cut into tiers wherever the smaller footprint of the remaining items lets one more
@@ -372,8 +486,6 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       const int m = (int)v.size();
       if (!m) continue;
       std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return taps(a) > taps(b); });
-      const int base = (int)flat.size();
-      flat.insert(flat.end(), v.begin(), v.end());
       std::vector<LmsRingCap> suf(m);
       for (int i = m - 1; i >= 0; i--)
         for (int q = 0; q < 4; q++) suf[i].c[q] = std::max(items[v[i]].p.vn[q] + 1, i + 1 < m ? suf[i + 1].c[q] : 0);
@@ -392,7 +504,9 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
           cut = lms_lds_bytes(k, nxt) > kLdsPerCu || (fit(i) > fit(first) && i - first >= 64 && m - i >= 64);
         }
         if (cut) {
-          lms_launches.push_back({k, g, base + first, i - first, cur});
+          const std::vector<int> lst = xcd_interleave(std::vector<int>(v.begin() + first, v.begin() + i), items);
+          lms_launches.push_back({k, g, (int)flat.size(), (int)lst.size(), cur});
+          flat.insert(flat.end(), lst.begin(), lst.end());
           first = i;
           if (i < m) for (int q = 0; q < 4; q++) cur.c[q] = items[v[i]].p.vn[q] + 1;
         } else cur = nxt;
@@ -418,7 +532,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     {
       double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
       Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
-      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], (int)idx_ols[k].size(), k, view(c), c->d_p.p);
+      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p);
     }
     HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
     HIPCHK(c, hipStreamWaitEvent(c->cls_stream[kMark], c->ev_ols[k], 0));
@@ -426,17 +540,35 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, hipEventRecord(sp_ols.b, c->cls_stream[kMark]));
   HIPCHK(c, hipEventRecord(c->ev_join[kMark], c->cls_stream[kMark]));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[kMark], 0));
+  // chase mode: the cascade kernels must not take the CUs before every OLS workgroup is resident (they would wait for
+  // producers that cannot start).  The OLS workgroups count themselves in; the host launches the cascade once all have
+  // begun -- or, if that does not happen within a second, falls back to ordering by the OLS completion events.
+  bool chasing = false;
+  if (chase) {
+    int n_ols_wg = 0;
+    for (int k = 0; k < kNumOlsClasses; k++) n_ols_wg += (int)idx_ols[k].size();
+    hipStream_t probe = g_streams[c->device & 63].lo_cls[sacamd_ctx::kSide - 1];   // a stream nothing long ever runs on
+    for (int tries = 0; tries < 2000 && !chasing; tries++) {
+      int begun = 0;
+      HIPCHK(c, hipMemcpyAsync(&begun, c->d_progress.p + count, sizeof(int), hipMemcpyDeviceToHost, probe));
+      HIPCHK(c, hipStreamSynchronize(probe));
+      if (begun >= n_ols_wg) chasing = true; else usleep(500);
+    }
+  }
+  PcmView pvl = pv;
+  if (!chasing) { pvl.progress = nullptr; pvl.started = nullptr; }
   bool lms_used[sacamd_ctx::kSide] = {};
   for (size_t q = 0; q < lms_launches.size(); q++) {
     const LmsLaunch &ll = lms_launches[q];
     const int si = kNumOlsClasses + (int)(q % kLmsStreams);
     hipStream_t st = c->cls_stream[si];
     if (!lms_used[si]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); lms_used[si] = true; }
-    for (int k = ll.group ? kFastOls : 0; k < (ll.group ? kNumOlsClasses : kFastOls); k++)
-      if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
-    double isteps = 0, fl = 0; for (int i = 0; i < ll.count; i++) { isteps += items[flat[ll.first + i]].n; fl += lms_flops(items[flat[ll.first + i]]); }
+    if (!chasing)
+      for (int k = ll.group ? kFastOls : 0; k < (ll.group ? kNumOlsClasses : kFastOls); k++)
+        if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
+    double isteps = 0, fl = 0; for (int i = 0; i < ll.count; i++) if (flat[ll.first + i] >= 0) { isteps += items[flat[ll.first + i]].n; fl += lms_flops(items[flat[ll.first + i]]); }
     Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps, fl);
-    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, view(c), c->d_tab.p, c->d_p.p, c->d_q.p);
+    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, pvl, c->d_tab.p, c->d_p.p, c->d_q.p);
   }
   for (int si = kNumOlsClasses; si < kMark; si++)
     if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], c->cls_stream[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
@@ -495,10 +627,17 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   sacamd_ctx *c = new sacamd_ctx();
   c->device = device; c->nch = nch; c->max_framesize = max_framesize; c->max_frames = max_frames;
   { const char *e = std::getenv("SACAMD_TRACE"); c->tracing = e && e[0] == '1'; }
-  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
-  for (int k = 0; k < sacamd_ctx::kSide; k++) {
-    if (hipStreamCreate(&c->cls_stream[k]) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
-  }
+  { const char *e = std::getenv("SACAMD_TAIL_HI"); if (e) c->tail_hi = e[0] != '0'; }
+  if (ensure_dev_streams(device, c->tail_hi != 0) != 0) { delete c; return SACAMD_ERR_HIP; }
+  // every context has its own main stream: generations of different contexts must not queue behind each other's
+  // serial bias / cost / copy phases (they share the pooled side streams, where the heavy kernels run)
+  if (hipStreamCreate(&c->own_main) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
+  { const char *e = std::getenv("SACAMD_TAIL_HI"); if (e) c->tail_hi = e[0] != '0'; }
+  { const char *e = std::getenv("SACAMD_CHASE"); if (e) c->chase = e[0] != '0'; }
+  { const char *e = std::getenv("SACAMD_TAIL_PRIO"); if (e) c->tail_prio = e[0] != '0'; }
+  set_lane(c, 0);
+  for (int k = 0; k < sacamd_ctx::kSide; k++)
+    if (hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   for (int k = 0; k < kNumOlsClasses; k++)
     if (hipEventCreateWithFlags(&c->ev_ols[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
@@ -518,13 +657,14 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c && c->tracing) std::fprintf(stderr, "[sacamd trace] search OLS streams: %lld distinct, %lld read from kept streams\n", c->ols_leaders, c->ols_kept_hits);
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); (void)hipStreamDestroy(c->stream); }
-  for (int k = 0; k < sacamd_ctx::kSide; k++) { if (c->cls_stream[k]) (void)hipStreamDestroy(c->cls_stream[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); }
+  if (c->own_main) (void)hipStreamDestroy(c->own_main);
+  for (int k = 0; k < sacamd_ctx::kSide; k++) if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   for (int k = 0; k < kNumOlsClasses; k++) if (c->ev_ols[k]) (void)hipEventDestroy(c->ev_ols[k]);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
-  c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
+  c->d_pred.release(); c->d_nf.release(); c->d_progress.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();

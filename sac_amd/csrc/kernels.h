@@ -11,6 +11,11 @@ struct PcmView {            // centred planar int32 PCM of the staged batch
   long long frame_stride, ch_stride;
   unsigned long long *prof;   // optional: 8 section cycle counters of the OLS kernel (debug)
   double *keep;               // kept p_lpc streams of earlier search generations (WorkItem::pin_kept), nullable
+  int *progress;              // final pass only (else null): per work-item count of p_lpc samples the OLS kernel has produced; the
+                              // cascade kernel of the item runs at the same time and follows it chunk by chunk
+  int *started;               // with progress: number of OLS workgroups that have begun (the host launches the cascade after all have)
+  int hiprio;                 // 1: latency-bound launch (final pass): its waves raise their issue priority (s_setprio) so that
+                              // throughput work sharing the CU (another batch's search) fills the gaps instead of slowing them
 };
 
 // ---- analyse (kernels_misc.hip)
@@ -49,7 +54,7 @@ struct CoderJob {
 };
 void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map /*jobs with_map*/, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv,
-                  unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len);
+                  unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len, int hiprio = 0);
 size_t coder_state_bytes();
 struct RemapJob {
   long long off;        // ints into pred / err / s2u_map planes

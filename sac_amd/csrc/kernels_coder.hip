@@ -23,8 +23,9 @@ size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
 
 __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJob *jobs, int count, const int *s2u, const int *s2u_map, const unsigned char *used,
                                                const unsigned short *laplace, const short *gfwd, const unsigned short *ginv,
-                                               unsigned char *state, size_t stride, unsigned char *out, int *len) {
+                                               unsigned char *state, size_t stride, unsigned char *out, int *len, int hiprio) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (hiprio) __builtin_amdgcn_s_setprio(3);
   CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
   coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJo
 
 void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv, unsigned char *d_state,
-                  size_t state_stride, unsigned char *d_out, int *d_len) {
+                  size_t state_stride, unsigned char *d_out, int *d_len, int hiprio) {
   if (count <= 0) return;
   {   // per DEVICE opt-in to > 64 KB dynamic LDS (idempotent; launchers may be called from several host threads)
     static std::atomic<unsigned long long> done{0};
@@ -68,7 +69,7 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   if (count > 512) { spw = 3; while (spw < kCoderStreamsPerWg && count > 256 * spw) spw++; }
   const int wgs = (count + spw - 1) / spw;
   hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_s2u_map, d_used, d_laplace,
-                     d_fwd, d_inv, d_state, state_stride, d_out, d_len);
+                     d_fwd, d_inv, d_state, state_stride, d_out, d_len, hiprio);
 }
 
 // ------------------------------------------------------------------ remap

@@ -62,15 +62,19 @@ void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab) {
 template <int NL, int NMAX>
 __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (idx[blockIdx.x] < 0) return;                 // padding entry of the XCD-interleaved launch list (host.hip, xcd_interleave)
   const WorkItem &it = items[idx[blockIdx.x]];
   const ChanParam p = it.p;
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
   ExecDev<NL> ex;
+  if (v.hiprio) __builtin_amdgcn_s_setprio(3);
   double *out = (it.pin_kept ? v.keep : pbuf) + it.off_pin;   // off_pin: where this item's p_lpc lives
-  if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
-  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
-  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
+  int *prog = v.progress ? v.progress + idx[blockIdx.x] : nullptr;
+  if (v.started && threadIdx.x == 0) atomicAdd(v.started, 1);
+  if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
+  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
+  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
 }
 
 template <int NL, int NMAX>
@@ -116,35 +120,40 @@ using LmsE = LmsClass<20, 4, 5, 1>;
 using LmsX = LmsClass<6, 10, 4, 2>;
 using LmsY = LmsClass<13, 5, 3, 1>;
 // canonical-order layouts of the final pass (pred_lms.h, CANON): odd slot counts (bank-conflict-free strided
-// ring reads); 7: (2304, 1280, 768, 256) taps on 256 lanes, 8: twice that on 512 lanes, 9: the profile maximum
+// ring reads), 256 lanes; 7: (2304, 1280, 768, 256) taps in one round over the lanes, 8 / 10: twice that in two rounds,
+// 9: four times (covers the profile maximum)
 using LmsK = LmsClass<9, 5, 3, 1>;
 using LmsL = LmsClass<17, 9, 5, 3>;
-// 7, 8: tables in LDS; 9: tables read from global memory (the fallback for anything that does not fit 7 / 8)
-constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : (cls == 9 ? 2 : 1); }
+// 7, 8: tables in LDS; 10 = the layout of 8 and 9 = the profile maximum, both with the tables read from global memory
+// (for what does not fit one CU's LDS with them)
+constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : (cls >= 9 ? 2 : 1); }
 template <int CLS> struct LmsCfg;
-template <> struct LmsCfg<0> { using C = LmsA; static constexpr int NL = 256, MINB = 1; };
-template <> struct LmsCfg<1> { using C = LmsB; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<2> { using C = LmsB; static constexpr int NL = 512, MINB = 1; };
-template <> struct LmsCfg<3> { using C = LmsD; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<4> { using C = LmsE; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<5> { using C = LmsX; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<6> { using C = LmsY; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 512, MINB = 1; };
-template <> struct LmsCfg<9> { using C = LmsL; static constexpr int NL = 512, MINB = 1; };
+template <> struct LmsCfg<0> { static constexpr int ROUNDS = 1; using C = LmsA; static constexpr int NL = 256, MINB = 1; };
+template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<2> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 512, MINB = 1; };
+template <> struct LmsCfg<3> { static constexpr int ROUNDS = 1; using C = LmsD; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<4> { static constexpr int ROUNDS = 1; using C = LmsE; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<5> { static constexpr int ROUNDS = 1; using C = LmsX; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<6> { static constexpr int ROUNDS = 1; using C = LmsY; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
+template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
+template <> struct LmsCfg<9> { using C = LmsK; static constexpr int NL = 256, MINB = 1, ROUNDS = 4; };
+template <> struct LmsCfg<10> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
 
 template <int CLS>
 __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NL = LmsCfg<CLS>::NL;
   using C = typename LmsCfg<CLS>::C;
+  if (idx[blockIdx.x] < 0) return;                 // padding entry of the XCD-interleaved launch list
   const WorkItem &it = items[idx[blockIdx.x]];
   const ChanParam &p = it.p;   // read through the scalar cache (uniform address); a private copy would live in scratch
   double sp[4];
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS)>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof);
+  if (v.hiprio) __builtin_amdgcn_s_setprio(3);
+  lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof, v.progress ? v.progress + it.ols_item : nullptr);
 }
 
 template <int CLS>
@@ -169,8 +178,9 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 5: return LmsLds<256, LmsX>::bytes(rc.c);
     case 6: return LmsLds<256, LmsY>::bytes(rc.c);
     case 7: return LmsLds<256, LmsK, 1>::bytes(rc.c);
-    case 8: return LmsLds<512, LmsK, 1>::bytes(rc.c);
-    case 9: return LmsLds<512, LmsL, 2>::bytes(rc.c);
+    case 8: return LmsLds<256, LmsK, 1>::bytes(rc.c);
+    case 9: return LmsLds<256, LmsK, 2>::bytes(rc.c);
+    case 10: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
   }
 }
@@ -182,8 +192,8 @@ int lms_class_for(const int *vn, bool canon) {
     // 7 / 8 keep mutab and powtab in LDS beside the histories (27 bytes per tap): they must fit one CU's LDS
     LmsRingCap rc; for (int q = 0; q < 4; q++) rc.c[q] = vn[q] + 1;
     if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3) && LmsLds<256, LmsK, 1>::bytes(rc.c) <= 160 * 1024) return 7;
-    if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3) && LmsLds<512, LmsK, 1>::bytes(rc.c) <= 160 * 1024) return 8;
-    return 9;
+    if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return LmsLds<256, LmsK, 1>::bytes(rc.c) <= 160 * 1024 ? 8 : 10;   // two rounds
+    return 9;                                                                                                               // four rounds
   }
   if (fits(256, LmsA::c0, LmsA::c1, LmsA::c2, LmsA::c3)) return 0;
   if (fits(256, LmsX::c0, LmsX::c1, LmsX::c2, LmsX::c3)) return 5;
@@ -195,7 +205,7 @@ int lms_class_for(const int *vn, bool canon) {
 }
 
 // register-file bound on resident workgroups per CU (237 / 256 / 256 registers, 4 / 4 / 8 waves)
-int lms_max_wg_per_cu(int lms_class) { return (lms_class == 2 || lms_class >= 8) ? 1 : 2; }
+int lms_max_wg_per_cu(int lms_class) { return (lms_class == 2 || lms_class == 9) ? 1 : 2; }
 
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, const double *d_p, double *d_q) {
@@ -210,6 +220,7 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 7: launch_lms_c<7>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 8: launch_lms_c<8>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 9: launch_lms_c<9>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 10: launch_lms_c<10>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     default: launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
   }
 }
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(64) void k_bias(const WorkItem *items, int count, P
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= count) return;
+  if (v.hiprio) __builtin_amdgcn_s_setprio(3);
   const WorkItem &it = items[i];
   const ChanParam p = it.p;
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;

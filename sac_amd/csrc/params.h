@@ -17,7 +17,7 @@ constexpr int kStages = 4;
 // regressor-length capacity of each OLS kernel instance; the last one is the two-wave generic path
 constexpr int kNumOlsClasses = 8;
 constexpr int kOlsClassMax[kNumOlsClasses] = {16, 24, 32, 40, 48, 56, 64, 96};
-constexpr int kNumLmsClasses = 10;   // 0..6 search layouts (free summation order), 7..9 canonical-order layouts of the final pass
+constexpr int kNumLmsClasses = 11;   // 0..6 search layouts (free summation order), 7..10 canonical-order layouts of the final pass
 constexpr int kLmsCanonFirst = 7;
 
 struct ChanParam {
@@ -50,7 +50,7 @@ struct WorkItem {
   long long off_p;    // doubles: this item's p_lpc stream in the OLS buffer and its p_lpc+p_lms stream in the cascade buffer [n]
   long long off_pin;  // doubles: where the cascade reads p_lpc (== off_p unless the OLS result is shared with another item)
   int pin_kept;       // 1: off_pin is relative to the context's buffer of kept search-window streams, not to the p_lpc buffer
-  int pad_;
+  int ols_item;       // index of the work-item whose OLS stage produces this item's p_lpc (itself unless shared)
   long long off_err;  // int32 residual [n]
   long long off_tab;  // doubles: per stage {mutab[vn], powtab[vn]}, stages back to back
   double sum_powtab[kStages];   // filled by the table kernel

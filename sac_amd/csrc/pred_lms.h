@@ -47,6 +47,13 @@ template <class C> constexpr int lms_group() { return C::total > 16 ? 2 : 4; }
 
 template <int N> struct DArr { double v[N]; };
 
+// f(std::integral_constant<int, I>{}) for I = 0 .. N-1: a loop whose index is a compile-time constant in every
+// iteration (register arrays indexed with it are never addressed dynamically, whatever the unroller decides)
+template <int I, int N, class F>
+SA_HD void static_for(F &&f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 // P-row dot of the RLS stage with a run-time order 1..10 but compile-time unrolling
 template <class A, class B>
 SA_HD double dot_canon_m(int m, A a, B b) {
@@ -147,10 +154,10 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
   return init;
 }
 
-template <class E, class C, int CANON = 0>
+template <class E, class C, int CANON = 0, int ROUNDS = 1>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
                      const int *self, int n, const double *pin_g, double *pout_g, char *lds_base, const int *ringcap,
-                     unsigned long long *prof = nullptr) {
+                     unsigned long long *prof = nullptr, const int *progress = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
   constexpr int kLmsChunk = NL;   // samples staged per global<->LDS exchange: one element per lane
@@ -160,17 +167,20 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // CANON geometry: the 8 dot chains are spread CPW per wave over LPC lanes each; the 4 power-sum chains
   // run on waves 0..3, 64 lanes each, with SMUL times the slots per lane
   static_assert(!CANON || NL == 256 || NL == 512, "canonical layout: 4 or 8 waves");
-  constexpr int CPW = CANON ? 8 / NW : 1, LPC = 64 / CPW, SMUL = CANON ? NL / 256 : 1;
+  // ROUNDS: a chain passes ROUNDS times over its lanes (positions r*LPC*J + m*J + j); the weights of all rounds stay in
+  // registers, the chain operands of one round at a time.  The power-sum chains (twice the positions, twice the lanes
+  // when NL = 256) make ROUNDS * SMUL rounds.
+  constexpr int CPW = CANON ? 8 / NW : 1, LPC = 64 / CPW, SMUL = CANON ? NL / 256 : 1, RD = CANON ? ROUNDS : 1, RP = RD * SMUL;
   constexpr int NX = CANON ? C::slots(0) : 1;      // chain operands of ONE stage at a time; stage 0 has the most slots
   static_assert(!CANON || (C::c0 >= C::c1 && C::c0 >= C::c2 && C::c0 >= C::c3), "stage 0 holds the most slots");
 
-  typename E::template Reg<DArr<C::total>> W;
+  typename E::template Reg<DArr<C::total * RD>> W;                // CANON: slot (stage s, round r, j) at C::first(s) * RD + r * J + j
   typename E::template Reg<DArr<CANON ? 1 : C::total>> MT, PT;   // CANON: the tables stay in LDS (read once per sample): the chain operands need the registers
-  typename E::template Reg<DArr<NX * SMUL>> PR;                 // CANON: powtab of this lane's power-chain taps, loaded for the duration of the chains
+  typename E::template Reg<DArr<NX>> PR;                 // CANON: powtab of this lane's power-chain taps, loaded for the duration of the chains
   typename E::template Reg<DArr<8>> acc;
   typename E::template Reg<DArr<CANON ? 4 : 1>> Wt;        // CANON: the chain's tail tap (taps beyond 8*floor(n/8)) of lanes m == 0
   typename E::template Reg<DArr<NX>> XD;                        // CANON: history values of this lane's dot-chain taps
-  typename E::template Reg<DArr<NX * SMUL>> XX;                 // CANON: squared history values of this lane's power-chain taps
+  typename E::template Reg<DArr<NX>> XX;                 // CANON: squared history values of this lane's power-chain taps
   typename E::template Reg<double> sd[4], sq[4], hop;           // CANON: running chain sums
 
   int ns[4], cap[4], pos[4];
@@ -206,7 +216,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         // dot layout: lane (wave w, half, m) owns positions m*J..m*J+J-1 of chain c = w*CPW + half, i.e. taps 8k + c;
         // positions >= K8 = n/8 are empty.  The chain's tail tap 8*K8 + c (if < n) sits in the extra slot of lane m == 0.
         const int K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
-        for (int j = 0; j < C::slots(s); j++) W[l].v[f + j] = 0.0;
+        for (int j = 0; j < C::slots(s) * RD; j++) W[l].v[f * RD + j] = 0.0;
         Wt[l].v[s] = 0.0;
         if constexpr (CANON == 1) for (int i = l; i < ns[s]; i += NL) { L.mt[s][ridx(i)] = tp[i]; L.pt[s][ridx(i)] = tp[ns[s] + i]; }
         if (l < 8) { const int ti = 4 * K4 + l; L.tailpw[s * 8 + l] = ti < ns[s] ? tp[ns[s] + ti] : 0.0; }
@@ -241,6 +251,11 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
 
   for (int t0 = 0; t0 < n; t0 += kLmsChunk) {
     // ---- stage a chunk of p_lpc / target in, flush the previous chunk of p_lpc+p_lms out
+    if (progress) {   // the OLS stage of this item is still running (final pass): wait until it has produced the chunk
+      const int need = t0 + kLmsChunk < n ? t0 + kLmsChunk : n;
+      ex.par([&](int l) { if ((l & 63) == 0) while (sa_acquire(progress) < need) sa_backoff(); });
+      ex.sync();
+    }
     ex.par([&](int l) {
       if (t0 > 0) pout_g[t0 - kLmsChunk + l] = L.pout[l];
       if (t0 + l < n) { L.pin[l] = pin_g[t0 + l]; L.sv[l] = self[t0 + l]; }
@@ -306,13 +321,6 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       // Canonical order (slmath::dot / calc_s2pow): weight update of this lane's chain positions, then the
       // running sums hop along the lanes of each chain.  After hop h the sum held by lane m <= h is final, so
       // after H = ceil(K / J) hops lane H-1 holds the chain total.
-      int Hd[4], Hp[4];
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0, K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
-        Hd[s] = (K8 + C::slots(s) - 1) / C::slots(s);
-        Hp[s] = (K4 + C::slots(s) * SMUL - 1) / (C::slots(s) * SMUL);
-      }
       // Stage by stage: power-sum chains (history squares + powtab in registers), then weight update and dot chains
       // (history values in registers).  Only one stage's chain operands are live at a time, and the loops between
       // the phases keep the compiler from hoisting every LDS load of the sample to the top (which spilled).
@@ -324,86 +332,110 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         const double *ring = L.ring[s];
         const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
         const int K8 = ns[s] >= 8 ? ns[s] >> 3 : 0, K4 = ns[s] >= 8 ? ns[s] >> 2 : 0;
-        ex.par([&](int l) {
-          const int lw = l & 63, c4 = l >> 6;
-          if (c4 < 4) {
+        // power-sum chains: chain c4 runs over the 64 lanes of wave c4, J positions per lane; with 512 lanes the chain
+        // makes SMUL = 2 rounds over the wave (positions r*64*J + lane*J + j), so that only J operand pairs are live
+        ex.par([&](int l) { sq[s][l] = 0.0; });
+        static_for<0, RP>([&](auto RC) {
+          constexpr int r = decltype(RC)::value;
+          const int kbase = r * 64 * C::slots(s);
+          if (kbase < K4 || r == 0) {
+            const int Hr = (K4 - kbase + C::slots(s) - 1) / C::slots(s) < 64 ? (K4 - kbase + C::slots(s) - 1) / C::slots(s) : 64;
+            ex.par([&](int l) {
+              const int lw = l & 63, c4 = l >> 6;
+              if (c4 < 4) {
 #pragma unroll
-            for (int j = 0; j < C::slots(s) * SMUL; j++) {
-              int tap = 4 * (lw * (C::slots(s) * SMUL) + j) + c4; tap = tap < last ? tap : last;
-              int in = ps + tap; if (in >= cp) in -= cp;
-              const double xs = ring[ridx(in)];
-              XX[l].v[j] = xs * xs;
-              const double pw = CANON == 2 ? tg[s][ns[s] + tap] : L.pt[s][ridx(tap)];                                     // positions >= K4 are empty
-              PR[l].v[j] = (lw * (C::slots(s) * SMUL) + j) < K4 ? pw : 0.0;
+                for (int j = 0; j < C::slots(s); j++) {
+                  const int k = kbase + lw * C::slots(s) + j;
+                  int tap = 4 * k + c4; tap = tap < last ? tap : last;
+                  int in = ps + tap; if (in >= cp) in -= cp;
+                  const double xs = ring[ridx(in)];
+                  XX[l].v[j] = xs * xs;
+                  const double pw = CANON == 2 ? tg[s][ns[s] + tap] : L.pt[s][ridx(tap)];
+                  PR[l].v[j] = k < K4 ? pw : 0.0;                                        // positions >= K4 are empty
+                }
+              }
+              if (r > 0) hop[l] = ex.wave_lane(sq[s], l, 63);     // the chain re-enters lane 0 with what lane 63 ended the last round with
+            });
+            for (int h = 0; h < Hr; h += 4) {
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                typename E::template Reg<double> sh = sq[s];
+                ex.shift_up1(sh);
+                ex.par([&](int l) {
+                  double a = (l & 63) == 0 ? (r > 0 ? hop[l] : 0.0) : sh[l];
+#pragma unroll
+                  for (int j = 0; j < C::slots(s); j++) a = fma(PR[l].v[j], XX[l].v[j], a);
+                  sq[s][l] = a;
+                });
+              }
             }
-          }
-          sq[s][l] = 0.0;
-        });
-        for (int h = 0; h < Hp[s]; h += 4) {
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            hop = sq[s];
-            ex.shift_up1(hop);
             ex.par([&](int l) {
-              double a = (l & 63) == 0 ? 0.0 : hop[l];
-#pragma unroll
-              for (int j = 0; j < C::slots(s) * SMUL; j++) a = fma(PR[l].v[j], XX[l].v[j], a);
-              sq[s][l] = a;
+              const int lw = l & 63, c4 = l >> 6;
+              if (Hr > 0 && c4 < 4 && lw == Hr - 1) L.psum[(par * 4 + s) * 4 + c4] = sq[s][l];
             });
           }
-        }
-        ex.par([&](int l) {
-          const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
-          const double wg = L.bc[s];
-#pragma unroll
-          for (int j = 0; j < C::slots(s); j++) {
-            int tap = 8 * (m * C::slots(s) + j) + c; tap = tap < last ? tap : last;
-            int in = ps + tap; if (in >= cp) in -= cp;
-            const double xn = ring[ridx(in)], xo = ring[ridx(in + 1)];
-            const double mu_t = (m * C::slots(s) + j) < K8 ? (CANON == 2 ? tg[s][tap] : L.mt[s][ridx(tap)]) : 0.0;   // positions >= K8 are empty: the weight stays 0
-            double w = fma(mu_t, wg * xo, W[l].v[f + j]);
-            w = clampd(w, -10.0, 10.0);
-            W[l].v[f + j] = w;
-            XD[l].v[j] = xn;
-          }
-          {   // the chain's tail tap (lanes m == 0; elsewhere mutab is 0 and the weight stays 0)
-            int tap = 8 * K8 + c; tap = tap < last ? tap : last;
-            int in = ps + tap; if (in >= cp) in -= cp;
-            const double xo = ring[ridx(in + 1)];
-            const double mu_t = (m == 0 && 8 * K8 + c < ns[s]) ? (CANON == 2 ? tg[s][tap] : L.mt[s][ridx(tap)]) : 0.0;
-            double w = fma(mu_t, wg * xo, Wt[l].v[s]);
-            w = clampd(w, -10.0, 10.0);
-            Wt[l].v[s] = w;
-            if (m == 0) L.tailw[(par * 4 + s) * 8 + c] = w;
-          }
-          sd[s][l] = 0.0;
         });
-        for (int h = 0; h < Hd[s]; h += 4) {
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            hop = sd[s];
-            ex.shift_up1(hop);
+        // dot chains: chain c runs over LPC lanes (CPW chains per wave), RD rounds; the weights are updated on the way
+        ex.par([&](int l) { sd[s][l] = 0.0; });
+        static_for<0, RD>([&](auto RC) {
+          constexpr int r = decltype(RC)::value;
+          const int kbase = r * LPC * C::slots(s);
+          if (kbase < K8 || r == 0) {
+            const int Hr = (K8 - kbase + C::slots(s) - 1) / C::slots(s) < LPC ? (K8 - kbase + C::slots(s) - 1) / C::slots(s) : LPC;
             ex.par([&](int l) {
-              double a = ((l & 63) % LPC) == 0 ? 0.0 : hop[l];
+              const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
+              const double wg = L.bc[s];
 #pragma unroll
-              for (int j = 0; j < C::slots(s); j++) a = fma(XD[l].v[j], W[l].v[f + j], a);
-              sd[s][l] = a;
+              for (int j = 0; j < C::slots(s); j++) {
+                const int k = kbase + m * C::slots(s) + j;
+                int tap = 8 * k + c; tap = tap < last ? tap : last;
+                int in = ps + tap; if (in >= cp) in -= cp;
+                const double xn = ring[ridx(in)], xo = ring[ridx(in + 1)];
+                const double mu_t = k < K8 ? (CANON == 2 ? tg[s][tap] : L.mt[s][ridx(tap)]) : 0.0;   // positions >= K8 are empty: the weight stays 0
+                double w = fma(mu_t, wg * xo, W[l].v[f * RD + r * C::slots(s) + j]);
+                w = clampd(w, -10.0, 10.0);
+                W[l].v[f * RD + r * C::slots(s) + j] = w;
+                XD[l].v[j] = xn;
+              }
+              if (r == 0) {   // the chain's tail tap (lanes m == 0; elsewhere mutab is 0 and the weight stays 0)
+                int tap = 8 * K8 + c; tap = tap < last ? tap : last;
+                int in = ps + tap; if (in >= cp) in -= cp;
+                const double xo = ring[ridx(in + 1)];
+                const double mu_t = (m == 0 && 8 * K8 + c < ns[s]) ? (CANON == 2 ? tg[s][tap] : L.mt[s][ridx(tap)]) : 0.0;
+                double w = fma(mu_t, wg * xo, Wt[l].v[s]);
+                w = clampd(w, -10.0, 10.0);
+                Wt[l].v[s] = w;
+                if (m == 0) L.tailw[(par * 4 + s) * 8 + c] = w;
+              }
+              if (r > 0) {   // re-enter lane 0 of the chain with its last lane's sum (uniform lane index per read)
+#pragma unroll
+                for (int q = 0; q < CPW; q++) { const double t_ = ex.wave_lane(sd[s], l, q * LPC + LPC - 1); if (lw / LPC == q) hop[l] = t_; }
+              }
+            });
+            for (int h = 0; h < Hr; h += 4) {
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                typename E::template Reg<double> sh = sd[s];
+                ex.shift_up1(sh);
+                ex.par([&](int l) {
+                  double a = ((l & 63) % LPC) == 0 ? (r > 0 ? hop[l] : 0.0) : sh[l];
+#pragma unroll
+                  for (int j = 0; j < C::slots(s); j++) a = fma(XD[l].v[j], W[l].v[f * RD + r * C::slots(s) + j], a);
+                  sd[s][l] = a;
+                });
+              }
+            }
+            ex.par([&](int l) {
+              const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC;
+              if (Hr > 0 && m == Hr - 1) L.csum[(par * 4 + s) * 8 + c] = sd[s][l];
             });
           }
-        }
+        });
       };
       canon_stage(std::integral_constant<int, 0>{}); canon_stage(std::integral_constant<int, 1>{});
       canon_stage(std::integral_constant<int, 2>{}); canon_stage(std::integral_constant<int, 3>{});
       SA_TICK(0);
       SA_TICK(1);
-      ex.par([&](int l) {
-        const int lw = l & 63, c = (l >> 6) * CPW + lw / LPC, m = lw % LPC, c4 = l >> 6;
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-          if (Hd[s] > 0 && m == Hd[s] - 1) L.csum[(par * 4 + s) * 8 + c] = sd[s][l];
-          if (Hp[s] > 0 && c4 < 4 && lw == Hp[s] - 1) L.psum[(par * 4 + s) * 4 + c4] = sq[s][l];
-        }
-      });
       }
       ex.sync();
       SA_TICK(2);

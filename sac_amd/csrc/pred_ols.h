@@ -124,7 +124,7 @@ struct OlsLdsFast {
 // j-1 terms, which do not need it, and consumed for the last term.
 template <class E, int NMAX>
 SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                          double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
+                          double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
   static_assert(E::nl == 64, "one-wave path");
   constexpr int nmax = NMAX;
   constexpr int S = NMAX + kOlsPad;   // column stride of Lq (rows NMAX.. are zero padding)
@@ -183,7 +183,7 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
       ff = one_m_lambda * c;
     });
-    ex.par([&](int l) { if (l == 0) p_out[t] = pred; });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
     SA_TICK(0);
     // covariance / rhs update (ols.cpp:38-45): lane = row i, loop over columns j <= i
     ex.par([&](int l) {
@@ -350,7 +350,7 @@ template <int N> struct OlsArr { double v[N]; };
 
 template <class E, int NMAX>
 SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                           double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
+                           double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
   constexpr int NL = E::nl;
   constexpr int PW = NL / 64;
   static_assert(PW == 4 || PW == 8, "panel width = number of waves");
@@ -416,7 +416,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
       ff = one_m_lambda * c;
     });
-    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; } });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
     ex.sync();
     SA_TICK(0);
     // covariance / rhs update (ols.cpp:38-45): lane = row, wave w takes the column groups 8w, 8w+8*PW, ..
@@ -574,7 +574,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
 // becomes a pair, broadcasts pick the half that owns the row.  One workgroup (four waves) per CU.
 template <class E, int NMAX>
 SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                            double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
+                            double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
   constexpr int NL = E::nl;
   constexpr int PW = NL / 64;
   static_assert(PW == 4 && NMAX > 64 && NMAX <= 128, "four waves, two rows per lane");
@@ -651,7 +651,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
       ff = one_m_lambda * c;
     });
-    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; } });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
     ex.sync();
     SA_TICK(0);
     // covariance / rhs update: lane = rows r, r+64; wave w takes the column groups 8w, 8w+32, ..

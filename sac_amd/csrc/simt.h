@@ -31,6 +31,28 @@
 
 namespace sacamd {
 
+// progress counters between a producer and a consumer KERNEL running at the same time (final pass: the cascade
+// follows the OLS stage chunk by chunk): release store / acquire load at device scope
+SA_HD void sa_publish(int *p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+SA_HD int sa_acquire(const int *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
+SA_HD void sa_backoff() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_sleep(32);
+#endif
+}
+
 // ------------------------------------------------------------------ emulation executor
 template <int NL>
 struct ExecEmu {
@@ -49,6 +71,8 @@ struct ExecEmu {
   void sync() {}
   template <class T> T lane_get(const Reg<T> &r, int k) { return r[k]; }
   double lane_bcast(const Reg<double> &r, int k) { return r[k]; }
+  // inside par(): the value lane k (0..63) of lane l's own wave holds
+  double wave_lane(const Reg<double> &r, int l, int k) { return r[(l & ~63) | k]; }
   int lane_geti(const Reg<int> &r, int k) { return r[k]; }
   // every lane takes the value of lane-1 (lane 0 keeps its own): DPP wave_shr:1 on the device
   void shift_up1(Reg<double> &r) { for (int l = NL - 1; l > 0; l--) r[l] = r[l - 1]; }
@@ -190,6 +214,7 @@ struct ExecDev {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(r.v), k & 63);
     return __hiloint2double(hi, lo);
   }
+  SA_D double wave_lane(const Reg<double> &r, int, int k) { return lane_bcast(r, k); }
   SA_D void allsum(Reg<double> &r, double *scratch) {
     constexpr int W = NL < 64 ? NL : 64;
     double v = r.v;

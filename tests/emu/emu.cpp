@@ -14,13 +14,13 @@
 using namespace sacamd;
 #define API extern "C" __attribute__((visibility("default")))
 
-template <class C, int NL = 256, int CANON = 0>
+template <class C, int NL = 256, int CANON = 0, int ROUNDS = 1>
 static void run_lms(const ChanParam &p, const double *sp, const double *tab, const int *self, int n, double *pio) {
   const int rc0[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};
   std::vector<char> lds(LmsLds<NL, C, CANON>::bytes(rc0), (char)0xFF);   // tight, as the launcher sizes the dynamic LDS; LDS is not zeroed on the device: start from NaN bit patterns
   ExecEmu<NL> *ex = new ExecEmu<NL>;
   const int rc[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};   // tight rings, as the host sizes them
-  lms_stage<ExecEmu<NL>, C, CANON>(*ex, p, sp, tab, self, n, pio, pio, lds.data(), rc);
+  lms_stage<ExecEmu<NL>, C, CANON, ROUNDS>(*ex, p, sp, tab, self, n, pio, pio, lds.data(), rc);
   delete ex;
 }
 
@@ -43,7 +43,13 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     {
 #define EMU_OLSP(NM) { std::vector<char> lds(ols_panel_lds_bytes(NM, 4)); ExecEmu<256> ex; ols_stage_panel<ExecEmu<256>, NM>(ex, p, self, other, n, pl, lds.data()); }
 #define EMU_OLS(NM) { std::vector<char> lds(OlsLdsFast::bytes(NM)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, NM>(ex, p, self, other, n, pl, lds.data()); }
-      if (p.n_ols <= 16) EMU_OLS(16)
+      if (!optimize) {     // as the host (build_items): the final pass uses the 32 / 64 / 96-tap capacity classes only
+        if (p.n_ols <= 32) EMU_OLS(32)
+        else if (p.n_ols <= 56) EMU_OLSP(56)
+        else if (p.n_ols <= 64) EMU_OLSP(64)
+        else { std::vector<char> lds(ols_panel2_lds_bytes(96)); ExecEmu<256> ex; ols_stage_panel2<ExecEmu<256>, 96>(ex, p, self, other, n, pl, lds.data()); }
+      }
+      else if (p.n_ols <= 16) EMU_OLS(16)
       else if (p.n_ols <= 24) EMU_OLS(24)
       else if (p.n_ols <= 32) EMU_OLS(32)
       else if (p.n_ols <= 40) EMU_OLSP(40)     // as the launcher: four-wave panel path from 33 on
@@ -64,8 +70,11 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     if (!optimize) {   // as the launcher (lms_class_for): the final pass sums in slmath::dot order
       const int rc[4] = {vn[0] + 1, vn[1] + 1, vn[2] + 1, vn[3] + 1};
       if (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256 && LmsLds<256, LmsClass<9, 5, 3, 1>, 1>::bytes(rc) <= 160 * 1024) run_lms<LmsClass<9, 5, 3, 1>, 256, 1>(p, sp, tab.data(), self, n, ps);
-      else if (vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512 && LmsLds<512, LmsClass<9, 5, 3, 1>, 1>::bytes(rc) <= 160 * 1024) run_lms<LmsClass<9, 5, 3, 1>, 512, 1>(p, sp, tab.data(), self, n, ps);
-      else run_lms<LmsClass<17, 9, 5, 3>, 512, 2>(p, sp, tab.data(), self, n, ps);
+      else if (vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) {
+        if (LmsLds<256, LmsClass<9, 5, 3, 1>, 1>::bytes(rc) <= 160 * 1024) run_lms<LmsClass<9, 5, 3, 1>, 256, 1, 2>(p, sp, tab.data(), self, n, ps);
+        else run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 2>(p, sp, tab.data(), self, n, ps);
+      }
+      else run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 4>(p, sp, tab.data(), self, n, ps);
     }
     else if (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) run_lms<LmsClass<8, 4, 2, 1>>(p, sp, tab.data(), self, n, ps);
     else if (vn[0] <= 1536 && vn[1] <= 2560 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<6, 10, 4, 2>>(p, sp, tab.data(), self, n, ps);
