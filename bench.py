@@ -82,20 +82,15 @@ def make_batch(nframes, seconds, seed0):
 
 def shard_frames(total_frames, rank, world, cost=None):
     """Frames of a corpus are independent units (--opt-reset).  Without costs: contiguous blocks.  With a
-    per-frame cost estimate C*(E*T_opt + T): longest-first onto the least loaded rank."""
+    per-frame cost estimate C*(E*T_opt + T): longest-first onto the least loaded rank, decided by
+    the library (sacamd_assign_frames, host only) so that every rank computes the same assignment."""
     if cost is None:
         per = (total_frames + world - 1) // world
         lo = min(rank * per, total_frames)
         return list(range(lo, min(lo + per, total_frames)))
-    order = sorted(range(total_frames), key=lambda f: (-cost[f], f))
-    load = [0.0] * world
-    mine = []
-    for f in order:
-        r = min(range(world), key=lambda q: (load[q], q))
-        load[r] += cost[f]
-        if r == rank:
-            mine.append(f)
-    return sorted(mine)
+    import sac_amd.api as api
+    owner = api.assign_frames(cost, world)
+    return [f for f in range(total_frames) if owner[f] == rank]
 
 
 def gather_records(recs, rank, world, device):
@@ -358,8 +353,20 @@ def main():
             cands[kname(kind, cls)] = (ms, launches, STAGE_BYTES[kind] * isteps, isteps, flops)
         cands["k_coder"] = (kt["coder"]["ms"], max(kt["coder"]["launches"], 1),
                             (4 + out["bps"] / 8) * n * 2 * args.frames * nsteps, 0.0, 0.0)
-        dom = max(cands, key=lambda k: cands[k][0])
+        # dominant kernel: the instance with the largest total launch time within the stage that spans most of the
+        # step (launches of different classes overlap, so their times do not add up; the OLS stage span is the longest)
+        fam = "k_ols" if kt["ols"]["ms"] >= max(kt["lms"]["ms"], kt["coder"]["ms"]) else ("k_lms" if kt["lms"]["ms"] >= kt["coder"]["ms"] else "k_coder")
+        dom = max((k for k in cands if k.startswith(fam)), key=lambda k: cands[k][0])
         dms, dlaunch, dbytes, disteps, dflops = cands[dom]
+        # HBM traffic per item-step of that kernel from the committed PMC pass (profiles/r02/pmc_hbm.json), if present
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_hbm.json")))
+            ent = pm["kernels"].get(dom.split(" (")[0])
+            if ent and disteps > 0:
+                traffic = (ent["fetch_bytes_per_item_step"] + ent["write_bytes_per_item_step"]) * disteps / max(dlaunch, 1)
+        except Exception:
+            pass
         avg_s = dms / 1e3 / max(dlaunch, 1)
         achieved = dbytes / max(dlaunch, 1) / avg_s / 1e9 if avg_s > 0 else 0.0
         # whole predictor: algorithmic fp64 flops of all OLS + cascade launches over the timed wall time
@@ -367,7 +374,9 @@ def main():
         wall_s = out["ms_per_step"] * nsteps / 1e3
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc pass on a smaller batch (profiles/r02/pmc_hbm.json: "
+                            "FETCH_SIZE + WRITE_SIZE per item-step of this kernel, scaled to this run's item-steps per launch); null = not collected",
             "launches": int(dlaunch), "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": dbytes / max(dlaunch, 1),
             "binds": "LDS instruction issue + dependent fp64 latency (neither HBM nor MFMA: ~1e4 flop/B, contractions <= 96 wide)",
             "fp64": {"kernel_gflops": dflops / (dms / 1e3) / 1e9 if dms > 0 else 0.0,

@@ -121,6 +121,12 @@ int sacamd_get_encoded(sacamd_ctx *ctx, int frame, int ch, uint8_t *out, int cap
 int sacamd_encode_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles_io, uint8_t *out,
                          long long cap, long long *rec_off /* [nframes+1] */);
 
+/* The search alone.  Replaces: FrameCoder::Optimize (libsac.cpp:365-427, called from Predict, :461-476) with OptDDS
+ * (opt/dds.cpp) for every staged frame.  profiles_io [nframes][58]: in = start point (ignored with cfg.reset != 0),
+ * out = the profile the search settled on.  Follow with sacamd_predict_final + sacamd_encode for the
+ * Predict() / Encode() split of the reference's FrameCoder (sac_amd/csrc/framecoder.h). */
+int sacamd_search_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles_io);
+
 /* ---- (7) adaptive sub-frame split -------------------------------------------------------------
  * Replaces: Codec::Analyse + AnalyseSparse + PushState (libsac/libsac.cpp:696-780) with SparsePCM::Analyse
  * (libsac/sparse.h:31-96): one read of samples_read samples per channel (planar int32, host memory, un-centred)
@@ -134,6 +140,13 @@ int sacamd_plan_subframes(sacamd_ctx *ctx, const int32_t *pcm_planar, long long 
 /* the PushState state machine alone (host only, no device work): block_state / block_len per block */
 int sacamd_subframes_from_states(const int *block_state, const int *block_len, int nblocks, int min_frame_length,
                                  sacamd_subframe *out, int cap, int *count);
+
+/* ---- multi-GPU sharding (host only) ----------------------------------------------------------
+ * Frames are independent units (with cfg.reset): owner[f] = rank that encodes frame f, assigned longest-first by the
+ * caller's cost estimate (channels * (evaluations * search window + frame length)) to the least loaded of `world`
+ * ranks.  Each rank stages its frames, runs sacamd_encode_frames and sends its records to rank 0 (the only
+ * communication on this path; bench.py: gather_records over torch.distributed == RCCL). */
+int sacamd_assign_frames(const double *cost, int nframes, int world, int *owner);
 
 /* ---- parity taps (tests) -------------------------------------------------------------------
  * Per-stage streams of one frame for one profile: p_lpc, p_lpc+p_lms (file-channel order),

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "sacamd_frames_attach_s16_device", "sacamd_analyse", "sacamd_get_stats", "sacamd_evaluate",
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
-    "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress",
+    "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
 ]
 
 
@@ -99,6 +99,17 @@ def subframes_from_states(block_state, block_len, min_frame_length):
     if rc != 0:
         raise SacAmdError(f"sacamd_subframes_from_states failed ({rc})")
     return [(out[i].start, out[i].length, out[i].state) for i in range(cnt.value)]
+
+
+def assign_frames(cost, world: int) -> np.ndarray:
+    """owner[f] = rank of frame f: longest-first by cost onto the least loaded rank (host only, no device)."""
+    lib = load_library()
+    c = np.ascontiguousarray(cost, np.float64)
+    owner = np.zeros(len(c), np.int32)
+    rc = lib.sacamd_assign_frames(_vp(c), len(c), int(world), _vp(owner))
+    if rc != 0:
+        raise SacAmdError(f"sacamd_assign_frames failed ({rc})")
+    return owner
 
 
 class Context:

@@ -106,12 +106,10 @@ class FrameCoder {
     chk(sacamd_frames_upload_i32(ctx_, 1, framesize_, buf.data(), (long long)numchannels_ * numsamples_, numsamples_, &numsamples_));
   }
   void run_search_and_final(const sacamd_cfg &c) {
-    // the search + final pass live behind sacamd_encode_frames; for the Predict()/Encode() split the
-    // same steps are issued individually: evaluate-driven search is done inside encode_frames, so use
-    // it for the profile and then re-run the final pass to expose the buffers.
-    std::vector<uint8_t> rec((size_t)numsamples_ * numchannels_ * 4 + 200000);
-    long long off[2];
-    chk(sacamd_encode_frames(ctx_, &c, base_profile.data(), rec.data(), (long long)rec.size(), off));
+    // FrameCoder::Predict (libsac.cpp:443-479): Optimize (the DDS search) -> base_profile, then the final pass
+    sacamd_default_profile(nullptr, nullptr, base_profile.data());
+    chk(sacamd_search_frames(ctx_, &c, base_profile.data()));
+    chk(sacamd_predict_final(ctx_, &c, base_profile.data()));
     int32_t st[8];
     chk(sacamd_get_stats(ctx_, st));
     for (int ch = 0; ch < numchannels_; ch++) { framestats[ch].mean = st[4 * ch]; framestats[ch].minval = st[4 * ch + 1]; framestats[ch].maxval = st[4 * ch + 2]; }

@@ -1054,6 +1054,22 @@ API int sacamd_progress(const sacamd_ctx *c, int *phase, int *generation) {
   return 0;
 }
 
+// Frames of a corpus are independent units (--opt-reset): hand them to `world` GPUs longest-first by estimated cost
+// (cost ~ channels * (evaluations * search window + frame length)), each to the least loaded rank.
+API int sacamd_assign_frames(const double *cost, int nframes, int world, int *owner) {
+  if (!cost || !owner || nframes < 0 || world < 1) return SACAMD_ERR_ARG;
+  std::vector<int> order(nframes);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  std::vector<double> load(world, 0.0);
+  for (int f : order) {
+    int r = 0;
+    for (int q = 1; q < world; q++) if (load[q] < load[r]) r = q;
+    load[r] += cost[f]; owner[f] = r;
+  }
+  return 0;
+}
+
 API int sacamd_eval_stats(sacamd_ctx *c, long long *out2, int reset) {
   if (!c || !out2) return SACAMD_ERR_ARG;
   out2[0] = c->eval_items; out2[1] = c->eval_hits;

@@ -124,9 +124,11 @@ using LmsY = LmsClass<13, 5, 3, 1>;
 // 9: four times (covers the profile maximum)
 using LmsK = LmsClass<9, 5, 3, 1>;
 using LmsL = LmsClass<17, 9, 5, 3>;
-// 7, 8: tables in LDS; 10 = the layout of 8 and 9 = the profile maximum, both with the tables read from global memory
-// (for what does not fit one CU's LDS with them)
-constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : (cls >= 9 ? 2 : 1); }
+// All canonical layouts read mutab / powtab from global memory (mode 2; L2-resident, one read per tap and sample): with
+// the tables in LDS (mode 1, 27 instead of 9 bytes per tap) only one workgroup fits a CU from ~4000 taps on and launches
+// had to be cut wherever the combined ring sizes of their items exceeded the LDS -- 56 launches serialised on four
+// streams in the 384 x 20 s run.  Measured per-step time is the same in both modes.
+constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : 2; }
 template <int CLS> struct LmsCfg;
 template <> struct LmsCfg<0> { static constexpr int ROUNDS = 1; using C = LmsA; static constexpr int NL = 256, MINB = 1; };
 template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 256, MINB = 2; };
@@ -177,8 +179,8 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 4: return LmsLds<256, LmsE>::bytes(rc.c);
     case 5: return LmsLds<256, LmsX>::bytes(rc.c);
     case 6: return LmsLds<256, LmsY>::bytes(rc.c);
-    case 7: return LmsLds<256, LmsK, 1>::bytes(rc.c);
-    case 8: return LmsLds<256, LmsK, 1>::bytes(rc.c);
+    case 7: return LmsLds<256, LmsK, 2>::bytes(rc.c);
+    case 8: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     case 9: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     case 10: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
@@ -189,11 +191,9 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
 int lms_class_for(const int *vn, bool canon) {
   auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
   if (canon) {
-    // 7 / 8 keep mutab and powtab in LDS beside the histories (27 bytes per tap): they must fit one CU's LDS
-    LmsRingCap rc; for (int q = 0; q < 4; q++) rc.c[q] = vn[q] + 1;
-    if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3) && LmsLds<256, LmsK, 1>::bytes(rc.c) <= 160 * 1024) return 7;
-    if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return LmsLds<256, LmsK, 1>::bytes(rc.c) <= 160 * 1024 ? 8 : 10;   // two rounds
-    return 9;                                                                                                               // four rounds
+    if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 7;     // one round over the lanes
+    if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 8;     // two rounds
+    return 9;                                                            // four rounds (profile maximum)
   }
   if (fits(256, LmsA::c0, LmsA::c1, LmsA::c2, LmsA::c3)) return 0;
   if (fits(256, LmsX::c0, LmsX::c1, LmsX::c2, LmsX::c3)) return 5;

@@ -68,12 +68,8 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     for (int t = 0; t < n; t++) ps[t] = pl[t];
     const int *vn = p.vn;
     if (!optimize) {   // as the launcher (lms_class_for): the final pass sums in slmath::dot order
-      const int rc[4] = {vn[0] + 1, vn[1] + 1, vn[2] + 1, vn[3] + 1};
-      if (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256 && LmsLds<256, LmsClass<9, 5, 3, 1>, 1>::bytes(rc) <= 160 * 1024) run_lms<LmsClass<9, 5, 3, 1>, 256, 1>(p, sp, tab.data(), self, n, ps);
-      else if (vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) {
-        if (LmsLds<256, LmsClass<9, 5, 3, 1>, 1>::bytes(rc) <= 160 * 1024) run_lms<LmsClass<9, 5, 3, 1>, 256, 1, 2>(p, sp, tab.data(), self, n, ps);
-        else run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 2>(p, sp, tab.data(), self, n, ps);
-      }
+      if (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256) run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 1>(p, sp, tab.data(), self, n, ps);
+      else if (vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 2>(p, sp, tab.data(), self, n, ps);
       else run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 4>(p, sp, tab.data(), self, n, ps);
     }
     else if (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) run_lms<LmsClass<8, 4, 2, 1>>(p, sp, tab.data(), self, n, ps);

@@ -138,6 +138,22 @@ out = bench.gather_records(recs, rank, world, torch.device("cpu"))
 if rank == 0:
     want = [bytes([f]) * (10 + 3 * f) for f in range(7)]
     assert out == want, (out, want)
+else:
+    assert out is None
+# cost-based assignment (sacamd_assign_frames, longest first): ragged frame counts per rank, frame order restored
+cost = [5.0, 1.0, 1.0, 1.0, 9.0, 2.0, 2.0, 0.5, 0.5]
+mine = bench.shard_frames(len(cost), rank, world, cost=cost)
+assert len(mine) == (3 if rank == 0 else 6), mine     # longest-first: rank 0 takes the 9 and two small frames
+recs = [bytes([f]) * (3 + 2 * f) for f in mine]
+out = bench.gather_records(recs, rank, world, torch.device("cpu"))
+owners = [None] * len(cost)
+import sac_amd.api as api
+ow = api.assign_frames(cost, world)
+if rank == 0:
+    # rank 0 receives rank-major order; put the records back into frame order with the same assignment
+    order = [f for r in range(world) for f in range(len(cost)) if ow[f] == r]
+    got = dict(zip(order, out))
+    assert [got[f] for f in range(len(cost))] == [bytes([f]) * (3 + 2 * f) for f in range(len(cost))]
     print("GATHER_OK")
 else:
     assert out is None

@@ -505,3 +505,21 @@ def test_headline_config_search_and_record_vs_reference(api, orc, golden_r2):
     assert hashlib.sha256(recs[0]).digest() == golden_r2["full100/record_sha256"].tobytes()
     dec, _ = orc.decode_frame(recs[0], 2, FULL_FRAMESIZE)
     assert np.array_equal(dec, raw)
+
+
+def test_framecoder_wrapper_writes_the_reference_records(api, golden, tmp_path):
+    """sac_amd/csrc/framecoder.h (the FrameCoder-shaped C++ class a maintainer links instead of the reference's) driven
+    by sac_amd/framecoder_test exactly like Codec::EncodeFile drives FrameCoder (libsac.cpp:788,822-829): fill
+    samples, SetNumSamples, Predict(), Encode(), WriteEncoded() -> the record equals the genuine reference's."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sac_amd", "framecoder_test")
+    assert os.path.exists(exe), "sac_amd/framecoder_test not built (make -C sac_amd/csrc)"
+    for name in ("s16_normal", "m8_normal", "s16_high_mt4", "s16_high_single"):
+        raw = golden[f"frame/{name}/raw"]
+        cfg = frame_cases()[name][1]
+        nch, n = raw.shape
+        inp = tmp_path / f"{name}.i32"; outp = tmp_path / f"{name}.rec"
+        np.ascontiguousarray(raw, np.int32).tofile(inp)
+        subprocess.run([exe, str(inp), str(nch), str(n), str(FRAMESIZE), str(cfg.optimize), repr(cfg.fraction), str(cfg.maxnfunc),
+                        str(cfg.num_threads), repr(cfg.sigma), str(outp)], check=True)
+        assert outp.read_bytes() == golden[f"frame/{name}/record"].tobytes(), name
