@@ -67,7 +67,7 @@ def make_batch(nframes, seconds, seed0):
     Synthesis is host work outside the timed region; it is spread over the host cores."""
     n = int(seconds * RATE)
     jobs = [(n, seed0 + i) for i in range(nframes)]
-    nproc = max(1, min(len(os.sched_getaffinity(0)), 32, nframes))
+    nproc = max(1, min(len(os.sched_getaffinity(0)), 32, nframes, int(os.environ.get("SAC_BENCH_SYNTH_PROCS", 32))))   # 1 under rocprofv3
     if nproc > 1 and nframes >= 8:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(nproc) as pool:    # before torch / HIP are initialised in this process

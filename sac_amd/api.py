@@ -252,6 +252,10 @@ class Context:
     def encode_pcm_files(self, files, rate, cfg: Cfg, max_framelen=20, adapt_block=True):
         """Batch driver: every frame of every file in one staged batch (frames are independent with
         cfg.reset=1).  files: list of int [nch, n] arrays.  Returns per file the list of frame records."""
+        if cfg.optimize and not cfg.reset:
+            raise SacAmdError("encode_pcm_files runs all frames of all files as one lock-step batch: frames cannot inherit the "
+                              "previous frame's profile (cfg.reset=0 == the reference without --opt-reset); pass reset=1, or chain "
+                              "encode_frames(profiles=...) per file yourself")
         plans = [self.plan_file(f, rate, max_framelen, adapt_block) for f in files]
         frames, owner = [], []
         for fi, (f, plan) in enumerate(zip(files, plans)):

@@ -120,7 +120,7 @@ using LmsE = LmsClass<20, 4, 5, 1>;
 using LmsX = LmsClass<6, 10, 4, 2>;
 using LmsY = LmsClass<13, 5, 3, 1>;
 // canonical-order layouts of the final pass (pred_lms.h, CANON): odd slot counts (bank-conflict-free strided
-// ring reads), 256 lanes; 7: (2304, 1280, 768, 256) taps in one round over the lanes, 8 / 10: twice that in two rounds,
+// ring reads), 256 lanes; 7: (2304, 1280, 768, 256) taps in one round over the lanes, 8: twice that in two rounds,
 // 9: four times (covers the profile maximum)
 using LmsK = LmsClass<9, 5, 3, 1>;
 using LmsL = LmsClass<17, 9, 5, 3>;
@@ -140,7 +140,6 @@ template <> struct LmsCfg<6> { static constexpr int ROUNDS = 1; using C = LmsY; 
 template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
 template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
 template <> struct LmsCfg<9> { using C = LmsK; static constexpr int NL = 256, MINB = 1, ROUNDS = 4; };
-template <> struct LmsCfg<10> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
 
 template <int CLS>
 __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {
@@ -182,7 +181,6 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 7: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     case 8: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     case 9: return LmsLds<256, LmsK, 2>::bytes(rc.c);
-    case 10: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
   }
 }
@@ -220,7 +218,6 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 7: launch_lms_c<7>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 8: launch_lms_c<8>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 9: launch_lms_c<9>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
-    case 10: launch_lms_c<10>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     default: launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
   }
 }

@@ -17,7 +17,7 @@ constexpr int kStages = 4;
 // regressor-length capacity of each OLS kernel instance; the last one is the two-wave generic path
 constexpr int kNumOlsClasses = 8;
 constexpr int kOlsClassMax[kNumOlsClasses] = {16, 24, 32, 40, 48, 56, 64, 96};
-constexpr int kNumLmsClasses = 11;   // 0..6 search layouts (free summation order), 7..10 canonical-order layouts of the final pass
+constexpr int kNumLmsClasses = 10;   // 0..6 search layouts (free summation order), 7..9 canonical-order layouts of the final pass
 constexpr int kLmsCanonFirst = 7;
 
 struct ChanParam {
