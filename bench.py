@@ -67,7 +67,8 @@ def make_batch(nframes, seconds, seed0):
     Synthesis is host work outside the timed region; it is spread over the host cores."""
     n = int(seconds * RATE)
     jobs = [(n, seed0 + i) for i in range(nframes)]
-    nproc = max(1, min(len(os.sched_getaffinity(0)), 32, nframes, int(os.environ.get("SAC_BENCH_SYNTH_PROCS", 32))))   # 1 under rocprofv3
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", 1))))
+    nproc = max(1, min(len(os.sched_getaffinity(0)) // ranks_here, 32, nframes, int(os.environ.get("SAC_BENCH_SYNTH_PROCS", 32))))   # 1 under rocprofv3
     if nproc > 1 and nframes >= 8:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(nproc) as pool:    # before torch / HIP are initialised in this process
@@ -214,7 +215,8 @@ def main():
     # then the range coder) that leaves most of the chip idle, so consecutive steps are software-pipelined
     # over --pipeline contexts (each with its own device buffers): step i runs on context i % depth, and while
     # one context is in its tail the next step's search fills the chip.  Every context stages the whole
-    # batch; the library lets one search run at a time per device and puts tails on high-priority streams.
+    # batch; the library lets one search run at a time per device.  Default depth 1: measured on MI355X the overlap does
+    # not pay (a dependent fp64 chain already keeps its SIMD's issue port ~70 % busy).
     depth = max(1, args.pipeline)
     ctxs = [api.Context(2, max(n, 16), args.frames, device=local_rank) for _ in range(depth)]
     frame_off = np.arange(args.frames, dtype=np.int64) * n

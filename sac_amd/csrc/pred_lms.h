@@ -238,6 +238,12 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   ex.sync();
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
   const double *tg[4] = {tab, tab + 2 * ns[0], tab + 2 * (ns[0] + ns[1]), tab + 2 * (ns[0] + ns[1] + ns[2])};   // per-stage {mutab, powtab} in global memory
+  int rmax8 = 0, rmax4 = 0;     // longest transform_reduce tails over the four stages (dot: n mod 8 or n < 8; power sum: n mod 4 or n < 8)
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int t8 = ns[s] >= 8 ? ns[s] & 7 : ns[s], t4 = ns[s] >= 8 ? ns[s] & 3 : ns[s];
+    rmax8 = t8 > rmax8 ? t8 : rmax8; rmax4 = t4 > rmax4 ? t4 : rmax4;
+  }
   // ring s starts ro1 + .. + ro_s doubles after ring[0]
   const int ro1 = (int)(L.ring[1] - L.ring[0]), ro2 = (int)(L.ring[2] - L.ring[1]), ro3 = (int)(L.ring[3] - L.ring[2]);
   // uniform mixer state (wave 0)
@@ -486,20 +492,20 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
             const int r8 = nsl - 8 * K8, r4 = nsl - 4 * K4, last = nsl - 1;
             auto hist = [&](int tap) { tap = tap < last ? tap : last; int in = ps + tap; if (in >= cs) in -= cs; return r0[ro + ridx(in)]; };
             const double *tw = L.tailw + (par * 4 + s) * 8, *tpw = L.tailpw + s * 8;
-            double xt[7], wt[7], xp[7], pt[7], q[8], r[4];
-#pragma unroll
-            for (int u = 0; u < 7; u++) { xt[u] = hist(8 * K8 + u); wt[u] = tw[u]; xp[u] = hist(4 * K4 + u); pt[u] = tpw[u]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) q[u] = L.csum[(par * 4 + s) * 8 + u];
-#pragma unroll
-            for (int u = 0; u < 4; u++) r[u] = L.psum[(par * 4 + s) * 4 + u];
+            // dot: chain sums, then the transform_reduce tail (canon.h tr_dot) on register operands, selects instead of
+            // branches; the power sum likewise afterwards (the two halves share their registers).  rmax8 / rmax4: the
+            // longest tail of any stage (uniform), so that short tails load nothing they do not need.
             a = 0.0; b = 0.0;
-            if (K8 > 0) {
-              const double q0 = q[0] + q[4], q1 = q[1] + q[5], q2 = q[2] + q[6], q3 = q[3] + q[7];
-              a = ((q0 + q1) + q2) + q3;
-              b = ((r[0] + r[1]) + r[2]) + r[3];
-            }
-            {   // transform_reduce tails (canon.h tr_dot / tr_s2pow) on register operands, selects instead of branches
+            {
+              double q[8], xt[7], wt[7];
+#pragma unroll
+              for (int u = 0; u < 8; u++) q[u] = L.csum[(par * 4 + s) * 8 + u];
+#pragma unroll
+              for (int u = 0; u < 7; u++) { xt[u] = 0.0; wt[u] = 0.0; if (u < rmax8) { xt[u] = hist(8 * K8 + u); wt[u] = tw[u]; } }
+              if (K8 > 0) {
+                const double q0 = q[0] + q[4], q1 = q[1] + q[5], q2 = q[2] + q[6], q3 = q[3] + q[7];
+                a = ((q0 + q1) + q2) + q3;
+              }
               const bool g4 = r8 >= 4;
               const double v1 = fma(xt[1], wt[1], xt[0] * wt[0]), v2 = fma(xt[3], wt[3], xt[2] * wt[2]);
               double init = g4 ? 0.0 + (v1 + v2) : 0.0;
@@ -514,6 +520,12 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
               a = a + init;
             }
             {
+              double r[4], xp[7], pt[7];
+#pragma unroll
+              for (int u = 0; u < 4; u++) r[u] = L.psum[(par * 4 + s) * 4 + u];
+#pragma unroll
+              for (int u = 0; u < 7; u++) { xp[u] = 0.0; pt[u] = 0.0; if (u < rmax4) { xp[u] = hist(4 * K4 + u); pt[u] = tpw[u]; } }
+              if (K8 > 0) b = ((r[0] + r[1]) + r[2]) + r[3];
               const bool g4 = r4 >= 4;
               const double v1 = fma(xp[1] * xp[1], pt[1], (xp[0] * xp[0]) * pt[0]), v2 = fma(xp[3] * xp[3], pt[3], (xp[2] * xp[2]) * pt[2]);
               double init = g4 ? 0.0 + (v1 + v2) : 0.0;
