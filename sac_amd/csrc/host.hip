@@ -28,6 +28,7 @@
 #include "dds_host.h"
 #include "kernels.h"
 #include "params.h"
+#include "pred_tables.h"
 
 using namespace sacamd;
 
@@ -332,9 +333,10 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
       if (!cd.optimize && c->tail_hi) it.ols_class = it.ols_class <= 2 ? 2 : (it.ols_class <= 5 ? 5 : it.ols_class);
       const int *vn = p.vn;
       it.lms_class = lms_class_for(vn, /*canon=*/!cd.optimize);   // the final pass (k = 1, what the decoder recomputes) sums in slmath::dot order
-      it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab;
+      it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab; it.off_tabc = -1;
       off_p += cd.n;
       for (int s = 0; s < 4; s++) off_tab += 2LL * vn[s];
+      if (it.lms_class >= kLmsCanonFirst) { it.off_tabc = off_tab; off_tab += canon_tab_doubles(canon_rounds_of_class(it.lms_class)); }
       items.push_back(it);
     }
   }
@@ -378,9 +380,13 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   const int count = (int)items.size();
   if (!count) return 0;
   long long tot_p = 0, tot_tab = 0;
-  for (auto &it : items) { tot_p = std::max(tot_p, it.off_p + it.n); tot_tab = std::max(tot_tab, it.off_tab); }
-  const WorkItem &last = items.back();
-  for (int s = 0; s < 4; s++) tot_tab += 2LL * last.p.vn[s];
+  for (auto &it : items) {
+    tot_p = std::max(tot_p, it.off_p + it.n);
+    long long e = it.off_tab;
+    for (int s = 0; s < 4; s++) e += 2LL * it.p.vn[s];
+    if (it.off_tabc >= 0) e = std::max(e, it.off_tabc + canon_tab_doubles(canon_rounds_of_class(it.lms_class)));
+    tot_tab = std::max(tot_tab, e);
+  }
   HIPCHK(c, c->d_items.ensure(count));
   HIPCHK(c, c->d_p.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_q.ensure((size_t)tot_p + 512));
@@ -936,7 +942,12 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
   // stage by stage so the OLS stream can be captured before the cascade overwrites it
   const int count = (int)items.size();
   long long tot_tab = 0;
-  for (auto &it : items) for (int s = 0; s < 4; s++) tot_tab += 2LL * it.p.vn[s];
+  for (auto &it : items) {
+    long long e = it.off_tab;
+    for (int s = 0; s < 4; s++) e += 2LL * it.p.vn[s];
+    if (it.off_tabc >= 0) e = std::max(e, it.off_tabc + canon_tab_doubles(canon_rounds_of_class(it.lms_class)));
+    tot_tab = std::max(tot_tab, e);
+  }
   HIPCHK(c, c->d_items.ensure(count)); HIPCHK(c, c->d_p.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_q.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_err.ensure((size_t)n * count + 512));
   HIPCHK(c, c->d_pred.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16)); HIPCHK(c, c->d_idx.ensure(count + 16));
   HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));

@@ -35,10 +35,21 @@ __global__ __launch_bounds__(256) void k_tables(WorkItem *items, double *tab) {
   const int ns = it.p.vn[s];
   double *mt = tab + off, *pt = tab + off + ns;
   const double mud = it.p.vmudecay[s], pwd = it.p.vpowdecay[s];
+  double *mtc = nullptr, *ptc = nullptr;        // lane-major copies for the canonical-order layouts (final pass)
+  int J = 1, n8 = 0, n4 = 0;
+  if (it.off_tabc >= 0) {
+    const int rounds = canon_rounds_of_class(it.lms_class);
+    long long oc = it.off_tabc;
+    for (int q = 0; q < s; q++) oc += canon_stage_doubles(q, rounds);
+    J = canon_slots(s);
+    mtc = tab + oc; ptc = mtc + (long long)rounds * J * kCanonNL;
+    n8 = ns >= 8 ? ns & ~7 : 0; n4 = ns >= 8 ? ns & ~3 : 0;
+  }
   for (int i = threadIdx.x; i < ns; i += 256) {
     double m, p;
     lms_table_entry(i, mud, pwd, &m, &p);
     mt[i] = m; pt[i] = p;
+    if (mtc) { if (i < n8) mtc[canon_mt_index(J, i)] = m; if (i < n4) ptc[canon_pt_index(J, i)] = p; }
   }
   double sum = 0.0;
   for (int b = 0; b < ns; b += 256) {
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(cons
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<NL> ex;
   if (v.hiprio) __builtin_amdgcn_s_setprio(3);
-  lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof, v.progress ? v.progress + it.ols_item : nullptr);
+  lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof, v.progress ? v.progress + it.ols_item : nullptr, it.off_tabc >= 0 ? tab + it.off_tabc : nullptr);
 }
 
 template <int CLS>

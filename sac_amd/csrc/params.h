@@ -53,6 +53,7 @@ struct WorkItem {
   int ols_item;       // index of the work-item whose OLS stage produces this item's p_lpc (itself unless shared)
   long long off_err;  // int32 residual [n]
   long long off_tab;  // doubles: per stage {mutab[vn], powtab[vn]}, stages back to back
+  long long off_tabc; // doubles: lane-major copies for the canonical-order layouts (pred_tables.h), -1 = none
   double sum_powtab[kStages];   // filled by the table kernel
   ChanParam p;
 };

@@ -30,6 +30,7 @@
 #include "canon.h"
 #include "libm_port.h"
 #include "params.h"
+#include "pred_tables.h"
 
 namespace sacamd {
 
@@ -157,7 +158,7 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
 template <class E, class C, int CANON = 0, int ROUNDS = 1>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
                      const int *self, int n, const double *pin_g, double *pout_g, char *lds_base, const int *ringcap,
-                     unsigned long long *prof = nullptr, const int *progress = nullptr) {
+                     unsigned long long *prof = nullptr, const int *progress = nullptr, const double *tabc = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
   constexpr int kLmsChunk = NL;   // samples staged per global<->LDS exchange: one element per lane
@@ -238,6 +239,14 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   ex.sync();
   const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
   const double *tg[4] = {tab, tab + 2 * ns[0], tab + 2 * (ns[0] + ns[1]), tab + 2 * (ns[0] + ns[1] + ns[2])};   // per-stage {mutab, powtab} in global memory
+  // CANON 2: lane-major copies (pred_tables.h): stage s = {mutab in dot order [RD*J][256], powtab in power-sum order [RD*J][256]}
+  const double *tcm[4], *tcp[4];
+  {
+    const double *q_ = tabc;
+#pragma unroll
+    for (int s = 0; s < 4; s++) { tcm[s] = q_; tcp[s] = q_ + (CANON ? ROUNDS : 1) * C::slots(s) * 256; q_ += 2 * (CANON ? ROUNDS : 1) * C::slots(s) * 256; }
+  }
+  static_assert(CANON != 2 || (NL == kCanonNL && C::c0 == canon_slots(0) && C::c1 == canon_slots(1) && C::c2 == canon_slots(2) && C::c3 == canon_slots(3)), "lane-major tables are laid out for the (9,5,3,1) x 256 layout");
   int rmax8 = 0, rmax4 = 0;     // longest transform_reduce tails over the four stages (dot: n mod 8 or n < 8; power sum: n mod 4 or n < 8)
 #pragma unroll
   for (int s = 0; s < 4; s++) {
@@ -356,7 +365,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
                   int in = ps + tap; if (in >= cp) in -= cp;
                   const double xs = ring[ridx(in)];
                   XX[l].v[j] = xs * xs;
-                  const double pw = CANON == 2 ? tg[s][ns[s] + tap] : L.pt[s][ridx(tap)];
+                  const double pw = CANON == 2 ? tcp[s][(r * C::slots(s) + j) * NL + l] : L.pt[s][ridx(tap)];
                   PR[l].v[j] = k < K4 ? pw : 0.0;                                        // positions >= K4 are empty
                 }
               }
@@ -397,7 +406,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
                 int tap = 8 * k + c; tap = tap < last ? tap : last;
                 int in = ps + tap; if (in >= cp) in -= cp;
                 const double xn = ring[ridx(in)], xo = ring[ridx(in + 1)];
-                const double mu_t = k < K8 ? (CANON == 2 ? tg[s][tap] : L.mt[s][ridx(tap)]) : 0.0;   // positions >= K8 are empty: the weight stays 0
+                const double mu_t = k < K8 ? (CANON == 2 ? tcm[s][(r * C::slots(s) + j) * NL + l] : L.mt[s][ridx(tap)]) : 0.0;   // positions >= K8 are empty: the weight stays 0
                 double w = fma(mu_t, wg * xo, W[l].v[f * RD + r * C::slots(s) + j]);
                 w = clampd(w, -10.0, 10.0);
                 W[l].v[f * RD + r * C::slots(s) + j] = w;

@@ -3,6 +3,7 @@
 // `-m "not gpu"` suite check the kernels' logic (right-looking LDLT, fused NLMS sweep, ring
 // indexing, stereo geometry ...) against the oracle without a GPU.  The product never builds
 // or loads this file.
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <vector>
@@ -15,12 +16,12 @@ using namespace sacamd;
 #define API extern "C" __attribute__((visibility("default")))
 
 template <class C, int NL = 256, int CANON = 0, int ROUNDS = 1>
-static void run_lms(const ChanParam &p, const double *sp, const double *tab, const int *self, int n, double *pio) {
+static void run_lms(const ChanParam &p, const double *sp, const double *tab, const int *self, int n, double *pio, const double *tabc = nullptr) {
   const int rc0[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};
   std::vector<char> lds(LmsLds<NL, C, CANON>::bytes(rc0), (char)0xFF);   // tight, as the launcher sizes the dynamic LDS; LDS is not zeroed on the device: start from NaN bit patterns
   ExecEmu<NL> *ex = new ExecEmu<NL>;
   const int rc[4] = {p.vn[0] + 1, p.vn[1] + 1, p.vn[2] + 1, p.vn[3] + 1};   // tight rings, as the host sizes them
-  lms_stage<ExecEmu<NL>, C, CANON, ROUNDS>(*ex, p, sp, tab, self, n, pio, pio, lds.data(), rc);
+  lms_stage<ExecEmu<NL>, C, CANON, ROUNDS>(*ex, p, sp, tab, self, n, pio, pio, lds.data(), rc, nullptr, nullptr, tabc);
   delete ex;
 }
 
@@ -68,9 +69,22 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     for (int t = 0; t < n; t++) ps[t] = pl[t];
     const int *vn = p.vn;
     if (!optimize) {   // as the launcher (lms_class_for): the final pass sums in slmath::dot order
-      if (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256) run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 1>(p, sp, tab.data(), self, n, ps);
-      else if (vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 2>(p, sp, tab.data(), self, n, ps);
-      else run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 4>(p, sp, tab.data(), self, n, ps);
+      // lane-major table copies as k_tables writes them for the canonical layouts (pred_tables.h)
+      const int rounds = (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256) ? 1 : ((vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) ? 2 : 4);
+      std::vector<double> tabc((size_t)canon_tab_doubles(rounds), std::nan(""));
+      {
+        size_t on = 0, oc = 0;
+        for (int s = 0; s < 4; s++) {
+          const int J = canon_slots(s), n8 = vn[s] >= 8 ? vn[s] & ~7 : 0, n4 = vn[s] >= 8 ? vn[s] & ~3 : 0;
+          double *mtc = &tabc[oc], *ptc = mtc + (size_t)rounds * J * kCanonNL;
+          for (int i = 0; i < n8; i++) mtc[canon_mt_index(J, i)] = tab[on + i];
+          for (int i = 0; i < n4; i++) ptc[canon_pt_index(J, i)] = tab[on + vn[s] + i];
+          on += 2 * (size_t)vn[s]; oc += (size_t)canon_stage_doubles(s, rounds);
+        }
+      }
+      if (rounds == 1) run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 1>(p, sp, tab.data(), self, n, ps, tabc.data());
+      else if (rounds == 2) run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 2>(p, sp, tab.data(), self, n, ps, tabc.data());
+      else run_lms<LmsClass<9, 5, 3, 1>, 256, 2, 4>(p, sp, tab.data(), self, n, ps, tabc.data());
     }
     else if (vn[0] <= 2048 && vn[1] <= 1024 && vn[2] <= 512 && vn[3] <= 256) run_lms<LmsClass<8, 4, 2, 1>>(p, sp, tab.data(), self, n, ps);
     else if (vn[0] <= 1536 && vn[1] <= 2560 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<6, 10, 4, 2>>(p, sp, tab.data(), self, n, ps);
