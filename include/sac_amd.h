@@ -7,10 +7,17 @@
  * a maintainer would add to the reference is shown in INTEGRATION.md.
  *
  * Conventions: every function returns 0 on success or a negative sacamd_status; nothing throws
- * across the ABI; the caller owns all host buffers; the context owns all device buffers and one
+ * across the ABI; the caller owns all host buffers; the context owns all device buffers and its main
  * HIP stream; a context is single-submitter (concurrency is expressed by batching frames and
- * candidates), distinct contexts are independent.  There is no CPU fallback: if no gfx950
- * device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
+ * candidates).  Distinct contexts hold independent state and may be driven from different threads; on one
+ * device they share a pool of 13 side streams (the hardware runs a limited number of queues at once) and
+ * take turns with their search phases (one search saturates the chip).  There is no CPU fallback: if no
+ * gfx950 device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
+ *
+ * Environment switches, all default off and all measured as losses on MI355X: SACAMD_TAIL_HI=1 runs the
+ * tail of a batch (final pass + coder) on two extra stream sets (SACAMD_POOL_PRIO=1: created with high priority),
+ * SACAMD_TAIL_PRIO=1 raises the wave priority of the tail kernels, SACAMD_CHASE=1 runs the final pass's cascade
+ * kernels concurrently with its OLS kernels.  SACAMD_TRACE=1 prints every predictor launch with its duration.
  */
 #ifndef SAC_AMD_H
 #define SAC_AMD_H

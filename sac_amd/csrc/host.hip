@@ -120,7 +120,7 @@ struct sacamd_ctx {
   // predictor scratch
   DevBuf<WorkItem> d_items;
   DevBuf<int> d_progress;     // final pass: per work-item OLS progress + [count] = number of OLS workgroups begun (PcmView::progress / started)
-  int chase = 1;              // SACAMD_CHASE: run the final pass's cascade kernels concurrently with its OLS kernels
+  int chase = 0;              // SACAMD_CHASE (default off, measured slower): run the final pass's cascade kernels concurrently with its OLS kernels
   DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist, d_nf;   // d_nf: per work-item "prediction not finite" flags of the last run_predict
   std::vector<int> h_nf;
   DevBuf<double> d_tab, d_p, d_q, d_cost;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
@@ -156,6 +156,15 @@ struct sacamd_ctx {
   int ols_keep_len = 0;                       // doubles per kept stream (the search window)
   long long ols_stamp = 0, ols_kept_hits = 0, ols_leaders = 0;
   bool ols_keep_on = false;                   // set by sacamd_evaluate around its run_predict call
+  // timing events are recycled (no event creation on the per-generation path once the pool has warmed up)
+  std::vector<hipEvent_t> ev_pool;
+  hipEvent_t get_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void put_event(hipEvent_t e) { if (e) ev_pool.push_back(e); }
   // timing
   std::vector<TimedSpan> spans;
   std::vector<TraceSpan> trace;
@@ -188,7 +197,7 @@ struct Span {
   sacamd_ctx *c; TimedSpan t;
   Span(sacamd_ctx *c_, int fam) : c(c_) {
     t.fam = fam;
-    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
+    t.a = c->get_event(); t.b = c->get_event();
     (void)hipEventRecord(t.a, c->stream);
   }
   ~Span() { (void)hipEventRecord(t.b, c->stream); c->spans.push_back(t); c->fam_launches[t.fam]++; }
@@ -200,8 +209,8 @@ void collect_spans(sacamd_ctx *c) {
     if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess && ms > 0) c->fam_ms[s.fam] += ms;
   }
   for (auto &s : c->spans) {
-    if (!s.shared_a) (void)hipEventDestroy(s.a);
-    (void)hipEventDestroy(s.b);
+    if (!s.shared_a) c->put_event(s.a);
+    c->put_event(s.b);
   }
   c->spans.clear();
   for (auto &t : c->trace) {
@@ -210,7 +219,7 @@ void collect_spans(sacamd_ctx *c) {
       c->cls_ms[t.kind][t.cls] += ms; c->cls_launches[t.kind][t.cls]++; c->cls_item_steps[t.kind][t.cls] += t.item_steps; c->cls_flops[t.kind][t.cls] += t.flops;
       if (c->tracing) std::fprintf(stderr, "[sacamd trace] %s %.3f ms\n", t.label, ms);
     }
-    (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+    c->put_event(t.a); c->put_event(t.b);
   }
   c->trace.clear();
 }
@@ -222,7 +231,7 @@ struct Trace {
     if (!on) return;
     std::snprintf(t.label, sizeof(t.label), "%s class %d items %d steps %d", what, cls, count, n);
     t.kind = what[0] == 'o' ? 0 : 1; t.cls = cls; t.item_steps = item_steps; t.flops = flops;
-    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
+    t.a = c->get_event(); t.b = c->get_event();
     (void)hipEventRecord(t.a, st);
   }
   ~Trace() { if (on) { (void)hipEventRecord(t.b, st); c->trace.push_back(t); } }
@@ -525,7 +534,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // stream 8 + q % 11, after the OLS events of its group ; the last side stream only marks "all OLS
   // done" for the timing spans ; the main stream joins everything before the bias stage.
   TimedSpan sp_ols{FAM_OLS, nullptr, nullptr}, sp_lms{FAM_LMS, nullptr, nullptr};
-  HIPCHK(c, hipEventCreate(&sp_ols.a)); HIPCHK(c, hipEventCreate(&sp_ols.b)); HIPCHK(c, hipEventCreate(&sp_lms.b));
+  sp_ols.a = c->get_event(); sp_ols.b = c->get_event(); sp_lms.b = c->get_event();
+  if (!sp_ols.a || !sp_ols.b || !sp_lms.b) return fail(c, SACAMD_ERR_HIP, "hipEventCreate failed");
   HIPCHK(c, hipEventRecord(sp_ols.a, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   constexpr int kMark = sacamd_ctx::kSide - 1, kLmsStreams = sacamd_ctx::kSide - 1 - kNumOlsClasses;
@@ -664,6 +674,8 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); }
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  c->ev_pool.clear();
   if (c->own_main) (void)hipStreamDestroy(c->own_main);
   for (int k = 0; k < sacamd_ctx::kSide; k++) if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   for (int k = 0; k < kNumOlsClasses; k++) if (c->ev_ols[k]) (void)hipEventDestroy(c->ev_ols[k]);
