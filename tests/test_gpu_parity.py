@@ -523,3 +523,28 @@ def test_framecoder_wrapper_writes_the_reference_records(api, golden, tmp_path):
         subprocess.run([exe, str(inp), str(nch), str(n), str(FRAMESIZE), str(cfg.optimize), repr(cfg.fraction), str(cfg.maxnfunc),
                         str(cfg.num_threads), repr(cfg.sigma), str(outp)], check=True)
         assert outp.read_bytes() == golden[f"frame/{name}/record"].tobytes(), name
+
+
+@pytest.mark.parametrize("env", [{"SACAMD_CHASE": "1"}, {"SACAMD_TAIL_HI": "1"}, {"SACAMD_TAIL_HI": "1", "SACAMD_TAIL_PRIO": "1"}])
+def test_optional_schedules_write_the_same_records(api, golden, tmp_path, env):
+    """The schedules that are off by default -- cascade chasing the OLS stage through progress counters,
+    the tail on its own stream sets with promoted OLS capacity classes, raised wave priority -- change WHEN kernels run,
+    never what they compute: same records as the genuine reference (a fresh process per setting: the switches are read
+    when a context is created)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import sac_amd.api as api\n"
+        "from golden_cases import FRAMESIZE, frame_cases\n"
+        f"g = np.load({os.path.join(root, 'tests', 'golden', 'ref_golden.npz')!r})\n"
+        "for name in ('s16_high_mt4', 'sparse16s_normal', 'm16_normal'):\n"
+        "    raw = g[f'frame/{name}/raw']; cfg = frame_cases()[name][1]\n"
+        "    ctx = api.Context(raw.shape[0], FRAMESIZE, 1); ctx.upload_i32([raw], FRAMESIZE)\n"
+        "    c = api.Cfg(cfg.optimize, cfg.sparse_pcm, cfg.zero_mean, cfg.reset, cfg.fraction, cfg.maxnfunc, cfg.num_threads, cfg.sigma, cfg.optk, cfg.cost)\n"
+        "    recs, _ = ctx.encode_frames(c); ctx.close()\n"
+        "    assert recs[0] == g[f'frame/{name}/record'].tobytes(), name\n"
+        "print('SCHEDULE_OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+    assert r.returncode == 0 and "SCHEDULE_OK" in r.stdout, r.stderr[-2000:]
