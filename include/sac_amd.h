@@ -17,7 +17,8 @@
  * Environment switches, all default off and all measured as losses on MI355X: SACAMD_TAIL_HI=1 runs the
  * tail of a batch (final pass + coder) on two extra stream sets (SACAMD_POOL_PRIO=1: created with high priority),
  * SACAMD_TAIL_PRIO=1 raises the wave priority of the tail kernels, SACAMD_CHASE=1 runs the final pass's cascade
- * kernels concurrently with its OLS kernels.  SACAMD_TRACE=1 prints every predictor launch with its duration.
+ * kernels concurrently with its OLS kernels, SACAMD_BIG_FIRST=1 launches the whole-CU cascade layout of the final pass
+ * before the others.  SACAMD_TRACE=1 prints every predictor launch with its duration.
  */
 #ifndef SAC_AMD_H
 #define SAC_AMD_H

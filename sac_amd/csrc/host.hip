@@ -120,6 +120,7 @@ struct sacamd_ctx {
   // predictor scratch
   DevBuf<WorkItem> d_items;
   DevBuf<int> d_progress;     // final pass: per work-item OLS progress + [count] = number of OLS workgroups begun (PcmView::progress / started)
+  int big_first = 0;          // SACAMD_BIG_FIRST (default off: measured no gain, 243.8 vs 242.2 s): final pass launches whole-CU cascade layouts before the two-per-CU ones
   int chase = 0;              // SACAMD_CHASE (default off, measured slower): run the final pass's cascade kernels concurrently with its OLS kernels
   DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist, d_nf;   // d_nf: per work-item "prediction not finite" flags of the last run_predict
   std::vector<int> h_nf;
@@ -461,8 +462,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   const bool chase = want_pred && c->chase && !c->ols_keep_on;
   PcmView pv = view(c);
   if (chase) {
-    HIPCHK(c, c->d_progress.ensure((size_t)count + 1));
-    HIPCHK(c, hipMemsetAsync(c->d_progress.p, 0, sizeof(int) * ((size_t)count + 1), c->stream));
+    HIPCHK(c, c->d_progress.ensure((size_t)count + 2));
+    HIPCHK(c, hipMemsetAsync(c->d_progress.p, 0, sizeof(int) * ((size_t)count + 2), c->stream));
     pv.progress = c->d_progress.p; pv.started = c->d_progress.p + count;
   }
   if (want_pred) HIPCHK(c, c->d_pred.ensure((size_t)tot_p + 512));
@@ -574,7 +575,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   PcmView pvl = pv;
   if (!chasing) { pvl.progress = nullptr; pvl.started = nullptr; }
   bool lms_used[sacamd_ctx::kSide] = {};
-  for (size_t q = 0; q < lms_launches.size(); q++) {
+  auto launch_one = [&](size_t q, const PcmView &pvq) -> int {
     const LmsLaunch &ll = lms_launches[q];
     const int si = kNumOlsClasses + (int)(q % kLmsStreams);
     hipStream_t st = c->cls_stream[si];
@@ -584,8 +585,46 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
         if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
     double isteps = 0, fl = 0; for (int i = 0; i < ll.count; i++) if (flat[ll.first + i] >= 0) { isteps += items[flat[ll.first + i]].n; fl += lms_flops(items[flat[ll.first + i]]); }
     Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps, fl);
-    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, pvl, c->d_tab.p, c->d_p.p, c->d_q.p);
+    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, pvq, c->d_tab.p, c->d_p.p, c->d_q.p);
+    return 0;
+  };
+  // Final pass: a layout whose workgroup needs a whole CU's registers (the four-round canonical class) can only start
+  // on a CU that has drained completely; launched together with the two-per-CU layouts its work-items would start
+  // tens of seconds late and become the tail of the pass.  So per OLS group: wait (host) for the group's OLS kernels,
+  // launch the whole-CU layouts, wait until all their workgroups have begun (they count themselves in), then the rest.
+  std::vector<char> launched(lms_launches.size(), 0);
+  if (want_pred && !chasing && c->big_first) {
+    if (!chase) HIPCHK(c, c->d_progress.ensure((size_t)count + 2));      // (with chase requested the buffer exists and is in use)
+    hipStream_t probe = g_streams[c->device & 63].lo_cls[sacamd_ctx::kSide - 1];
+    HIPCHK(c, hipMemsetAsync(c->d_progress.p + count + 1, 0, sizeof(int), probe));
+    HIPCHK(c, hipStreamSynchronize(probe));
+    int expected = 0;
+    for (int g = 0; g < 2; g++) {
+      std::vector<size_t> big, rest;
+      for (size_t q = 0; q < lms_launches.size(); q++)
+        if (lms_launches[q].group == g) (lms_max_wg_per_cu(lms_launches[q].cls) == 1 ? big : rest).push_back(q);
+      if (big.empty() || rest.empty()) continue;
+      for (int k = g ? kFastOls : 0; k < (g ? kNumOlsClasses : kFastOls); k++)
+        if (!idx_ols[k].empty()) HIPCHK(c, hipEventSynchronize(c->ev_ols[k]));
+      PcmView pvb = pvl;
+      pvb.started = c->d_progress.p + count + 1;
+      for (size_t q : big) {
+        for (int i = 0; i < lms_launches[q].count; i++) if (flat[lms_launches[q].first + i] >= 0) expected++;
+        int r = launch_one(q, pvb); if (r) return r;
+        launched[q] = 1;
+      }
+      for (int tries = 0; tries < 4000; tries++) {       // <= 2 s; on timeout the rest is launched anyway
+        int begun = 0;
+        HIPCHK(c, hipMemcpyAsync(&begun, c->d_progress.p + count + 1, sizeof(int), hipMemcpyDeviceToHost, probe));
+        HIPCHK(c, hipStreamSynchronize(probe));
+        if (begun >= expected) break;
+        usleep(500);
+      }
+      for (size_t q : rest) { int r = launch_one(q, pvl); if (r) return r; launched[q] = 1; }
+    }
   }
+  for (size_t q = 0; q < lms_launches.size(); q++)
+    if (!launched[q]) { int r = launch_one(q, pvl); if (r) return r; }
   for (int si = kNumOlsClasses; si < kMark; si++)
     if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], c->cls_stream[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
   HIPCHK(c, hipEventRecord(sp_lms.b, c->stream));
@@ -650,6 +689,7 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   if (hipStreamCreate(&c->own_main) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
   { const char *e = std::getenv("SACAMD_TAIL_HI"); if (e) c->tail_hi = e[0] != '0'; }
   { const char *e = std::getenv("SACAMD_CHASE"); if (e) c->chase = e[0] != '0'; }
+  { const char *e = std::getenv("SACAMD_BIG_FIRST"); if (e) c->big_first = e[0] != '0'; }
   { const char *e = std::getenv("SACAMD_TAIL_PRIO"); if (e) c->tail_prio = e[0] != '0'; }
   set_lane(c, 0);
   for (int k = 0; k < sacamd_ctx::kSide; k++)

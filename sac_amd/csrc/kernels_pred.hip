@@ -165,6 +165,7 @@ __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(cons
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<NL> ex;
   if (v.hiprio) __builtin_amdgcn_s_setprio(3);
+  if (v.started && !v.progress && threadIdx.x == 0) atomicAdd(v.started, 1);    // "this workgroup has begun" (host.hip: whole-CU layouts first)
   lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof, v.progress ? v.progress + it.ols_item : nullptr, it.off_tabc >= 0 ? tab + it.off_tabc : nullptr);
 }
 
