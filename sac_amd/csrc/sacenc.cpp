@@ -2,12 +2,14 @@
 //
 //   sacenc [--normal|--high|--veryhigh|--extrahigh|--best|--insane] [--opt-cfg=dds,N] [--framelen=S]
 //          [--adapt-block=no] [--max-frames=N] in.wav [more.wav ...] out.sac|outdir
+//   sacenc --list|--listfull file.sac       header, ratio, MD5 (and every frame record) as the reference's --list / --listfull
 //
 // The encode side of the reference's command line (/root/reference/src/cmdline.cpp:127-235) and of
 // Codec::EncodeFile (libsac/libsac.cpp:782-855): reads of framelen seconds, adaptive sub-frame split
 // (sacamd_plan_subframes), every frame of every input file staged as ONE batch per max-frames
 // (frames are independent: --opt-reset semantics), records written behind the SAC2 header + MD5.
 // With several inputs the last argument is a directory.  Host code only; no CPU compute path.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +36,7 @@ int main(int argc, char **argv) {
     sacamd_cfg cfg; sacamd_default_cfg(&cfg);
     cfg.reset = 1;
     int framelen = 20, adapt_block = 1, max_frames = 256;
+    int list_mode = 0;             // 1: --list, 2: --listfull (host only)
     bool header_only = false;      // --header-only: write header + MD5 of each input and stop (no device needed; tests)
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
@@ -50,8 +53,37 @@ int main(int argc, char **argv) {
       else if (a == "--adapt-block=no" || a == "--adapt-block=0") adapt_block = 0;
       else if (a.rfind("--max-frames=", 0) == 0) max_frames = std::atoi(a.c_str() + 13);
       else if (a == "--header-only") header_only = true;
+      else if (a == "--list") list_mode = 1;
+      else if (a == "--listfull") list_mode = 2;
       else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
       else pos.push_back(a);
+    }
+    if (list_mode) {               // cmdline.cpp:295-323 + Codec::ScanFrames (libsac.cpp:659-693)
+      if (pos.size() != 1) { std::cerr << "usage: sacenc --list|--listfull file.sac\n"; return 2; }
+      const std::vector<uint8_t> raw = slurp(pos[0]);
+      SacHeader h;
+      if (!read_sac_header(raw, h)) { std::cout << "warning: input is not a valid .sac file\n"; return 1; }
+      const double bps = (double)raw.size() * 8.0 / ((double)h.numsamples * h.numchannels);
+      std::printf("Open: '%s': ok (%zu Bytes)\n", pos[0].c_str(), raw.size());
+      std::printf("  WAVE  Codec: PCM (%d kbps)\n", (int)std::lround(h.samplerate * h.numchannels * bps / 1000.0));
+      std::printf("  %dHz %d Bit  %d channel(s)  %d samples  metadata %d bytes\n", h.samplerate, h.bitspersample, h.numchannels, h.numsamples, h.metadatasize);
+      std::printf("  Profile: %ds\n  Ratio:   %.3f bps\n\n  Audio MD5: ", h.max_framelen, bps);
+      for (int i = 0; i < 16; i++) std::printf("%x", h.md5[i]);
+      std::printf("\n");
+      if (list_mode == 2) {
+        std::vector<SacFrameInfo> fr; long long ch = 0, bh = 0;
+        const bool ok = scan_sac_frames(raw, h, fr, &ch, &bh);
+        for (size_t i = 0; i < fr.size(); i++) {
+          std::printf("Frame %zu: %d samples \n", i + 1, fr[i].numsamples);
+          for (int c = 0; c < h.numchannels && c < 2; c++) {
+            std::printf("  Channel %d: %d bytes\n    Bpn: %d, sparse_pcm: %d\n    mean: %d, min: %d, max: %d\n", c, fr[i].ch[c].blocksize, fr[i].ch[c].maxbpn,
+                        fr[i].ch[c].mapped, fr[i].ch[c].mean, fr[i].ch[c].minval, fr[i].ch[c].maxval);
+          }
+        }
+        std::printf("Frames   %zu\nHdr_size %lld (coefs %lld,block %lld)\n", fr.size(), ch + bh, ch, bh);
+        if (!ok) { std::printf("warning: truncated frame record\n"); return 1; }
+      }
+      return 0;
     }
     if (pos.size() < 2 || framelen < 1 || framelen > 255 || max_frames < 1) { std::cerr << "usage: sacenc [options] in.wav [more.wav ...] out.sac|outdir\n"; return 2; }
     const std::string outarg = pos.back(); pos.pop_back();

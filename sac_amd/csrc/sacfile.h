@@ -156,4 +156,38 @@ inline std::vector<uint8_t> sac_header_and_md5(const WavInfo &w, int max_framele
   return h;
 }
 
+// ---- reading side used by `sacenc --list / --listfull` (cmdline.cpp:295-323, Codec::ScanFrames libsac.cpp:659-693)
+struct SacHeader { int numchannels = 0, samplerate = 0, bitspersample = 0, numsamples = 0, max_framelen = 0, metadatasize = 0; uint8_t md5[16] = {}; size_t frames_at = 0; };
+inline bool read_sac_header(const std::vector<uint8_t> &raw, SacHeader &h) {
+  if (raw.size() < 22 || std::memcmp(raw.data(), "SAC2", 4) != 0) return false;
+  h.numchannels = rd16(&raw[4]); h.samplerate = (int)rd32(&raw[6]); h.bitspersample = rd16(&raw[10]); h.numsamples = (int)rd32(&raw[12]);
+  h.max_framelen = raw[16]; h.metadatasize = (int)rd32(&raw[18]);
+  const size_t p = 22 + (size_t)h.metadatasize;
+  if (raw.size() < p + 16) return false;
+  std::memcpy(h.md5, &raw[p], 16);
+  h.frames_at = p + 16;
+  return true;
+}
+struct SacFrameInfo { int numsamples; struct Ch { int blocksize, mean, minval, maxval, maxbpn, mapped; } ch[2]; };
+// walks the frame records (WriteEncoded layout: u32 numsamples, 58 x f32 profile, per channel u32 blocksize, mean, min,
+// max, u16 flag (bit 9 = mapped, low byte = maxbpn), payload); false on a truncated file
+inline bool scan_sac_frames(const std::vector<uint8_t> &raw, const SacHeader &h, std::vector<SacFrameInfo> &out, long long *coef_hdr, long long *block_hdr) {
+  size_t p = h.frames_at;
+  *coef_hdr = *block_hdr = 0;
+  while (p < raw.size()) {
+    if (p + 4 + 58 * 4 > raw.size()) return false;
+    SacFrameInfo f{}; f.numsamples = (int)rd32(&raw[p]); p += 4 + 58 * 4; *coef_hdr += 58 * 4;
+    for (int c = 0; c < h.numchannels && c < 2; c++) {
+      if (p + 18 > raw.size()) return false;
+      const uint16_t flag = rd16(&raw[p + 16]);
+      f.ch[c] = {(int)rd32(&raw[p]), (int)rd32(&raw[p + 4]), (int)rd32(&raw[p + 8]), (int)rd32(&raw[p + 12]), flag & 0xff, (flag >> 9) & 1};
+      p += 18; *block_hdr += 18;
+      if (p + (size_t)f.ch[c].blocksize > raw.size()) return false;
+      p += (size_t)f.ch[c].blocksize;
+    }
+    out.push_back(f);
+  }
+  return true;
+}
+
 }  // namespace sacamd

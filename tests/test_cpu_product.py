@@ -261,3 +261,29 @@ def test_cpp_container_header_matches_python(tmp_path):
         subprocess.run([exe, "--header-only", "--framelen=7", str(wav), str(out)], check=True)
         w = C.parse_wav(blob)
         assert out.read_bytes() == C.sac_header(w, 7) + hashlib.md5(w.data).digest()
+
+
+def test_sacenc_list_reads_a_sac_file(orc, tmp_path):
+    """`sacenc --listfull` (host only; the reference's --list / --listfull, cmdline.cpp:295-323 + Codec::ScanFrames) on a
+    .sac file written by sac_amd.container from oracle records: header fields, MD5, frame count and block sizes."""
+    import hashlib
+    from sac_amd import container as C
+    from sac_amd.synth import synth_pcm
+    exe = os.path.join(ROOT, "sac_amd", "sacenc")
+    rate, maxlen = 8000, 1
+    pcm = synth_pcm(2 * rate + 345, 2, 9, rate)
+    w = C.parse_wav(C.wav_bytes_from_pcm(pcm, rate, 16))
+    recs, pos = [], 0
+    while pos < w.numsamples:
+        n = min(maxlen * rate, w.numsamples - pos)
+        recs.append(orc.encode_frame(pcm[:, pos: pos + n], frame_cfg("normal"), maxlen * rate)["record"])
+        pos += n
+    path = str(tmp_path / "t.sac")
+    C.write_sac(path, w, maxlen, recs)
+    out = subprocess.run([exe, "--listfull", path], capture_output=True, text=True, check=True).stdout
+    assert f"{rate}Hz 16 Bit  2 channel(s)  {w.numsamples} samples" in out
+    assert "Audio MD5: " + "".join("%x" % b for b in hashlib.md5(w.data).digest()) in out
+    assert f"Frames   {len(recs)}" in out
+    for i, r in enumerate(recs):
+        assert f"Frame {i + 1}: {int.from_bytes(r[:4], 'little')} samples" in out
+        assert f"Channel 0: {int.from_bytes(r[4 + 232: 8 + 232], 'little')} bytes" in out
