@@ -35,8 +35,8 @@ import time
 
 T_PROC_START = time.time()
 
-# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); every context here
-# uses 21 streams (main + one per kernel class) and several contexts may run concurrently.
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the library keeps a pool of
+# 14 streams per device (one per kernel class) plus one main stream per context.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np

@@ -49,6 +49,10 @@ _PRESETS = {  # cmdline.cpp:127-156
 
 def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, fraction=None,
              maxnfunc=None, cost=None, optk=4, sigma=None) -> Cfg:
+    """A preset of the reference's command line (cmdline.cpp:127-156) as a Cfg.  Note reset=1 (== --opt-reset) is the
+    default HERE because the batch drivers run all frames in lock-step: with reset=0 (the reference's default, and what
+    sacamd_default_cfg returns) a frame's search starts from the profile the caller passes in profiles_io, so chaining
+    "best profile of frame f seeds frame f+1" is the caller's job, one frame of a file at a time."""
     o, f, e, s, c = _PRESETS[mode]
     return Cfg(o, sparse_pcm, zero_mean, reset, f if fraction is None else fraction,
                e if maxnfunc is None else maxnfunc, num_threads, s if sigma is None else sigma, optk,
