@@ -287,3 +287,26 @@ def test_sacenc_list_reads_a_sac_file(orc, tmp_path):
     for i, r in enumerate(recs):
         assert f"Frame {i + 1}: {int.from_bytes(r[:4], 'little')} samples" in out
         assert f"Channel 0: {int.from_bytes(r[4 + 232: 8 + 232], 'little')} bytes" in out
+
+
+@pytest.mark.parametrize("taps", [(2304, 1280, 768, 256), (2305, 1280, 768, 256), (2304, 1281, 767, 9), (4608, 2560, 1536, 512),
+                                  (4609, 8, 8, 8), (264, 2561, 15, 2), (8, 8, 1537, 513), (7, 6, 5, 4), (9216 - 1, 33, 4, 2)])
+def test_canonical_cascade_layout_boundaries_emulated_vs_oracle(emu, orc, taps):
+    """The canonical-order cascade at the capacity boundaries of its three layouts (one, two and four rounds over the
+    lanes), with stage lengths just below / at / above 8 and ragged everywhere: emulated kernel body == oracle, bit for
+    bit (the oracle itself is pinned to the genuine reference on the round-2 traces)."""
+    from sac_amd.synth import synth_pcm
+    taps = tuple(min(t, c) for t, c in zip(taps, (8192, 4096, 2048, 1024)))
+    n = 160
+    raw = synth_pcm(n, 1, 77 + sum(taps) % 13, 8000)
+    g = np.ascontiguousarray(orc.profile()[:, 2].copy(), np.float32)
+    g[28], g[29], g[30], g[37] = taps
+    smp, stats = center_frame(raw)
+    plpc = np.zeros((1, n)); psum = np.zeros((1, n)); err = np.zeros((1, n), np.int32); pred = np.zeros((1, n), np.int32)
+    rc = emu.emu_predict(1, n, _vp(np.ascontiguousarray(smp, np.int32)), _vp(np.ascontiguousarray(stats, np.int32)), _vp(g), 0, n, 0, 4,
+                         _vp(plpc), _vp(psum), _vp(err), _vp(pred))
+    assert rc == 0
+    pd, ol, om, oe = orc.predict_trace(smp, stats, g, 0, n, 0)
+    assert np.array_equal(plpc.view(np.uint64), ol.view(np.uint64))
+    assert np.array_equal(psum.view(np.uint64), (ol + om).view(np.uint64))
+    assert np.array_equal(err, oe)
