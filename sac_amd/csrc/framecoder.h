@@ -4,8 +4,10 @@
 // for the ENCODE path so that Codec::EncodeFile (libsac/libsac.cpp:782-855) can drive it unchanged:
 //   FrameCoder(numchannels, framesize, cfg); samples[ch][0..n); SetNumSamples(n); Predict();
 //   Encode(); WriteEncoded(fout) -- same names, same argument meaning, same public buffers.
-// Differences that come from batching: AddFrame()/Flush() let a caller stage many frames before the
-// GPU runs them together; Predict()/Encode() on a single staged frame behave like the reference.
+// One frame per Predict()/Encode() pair, like the reference; base_profile is carried from frame to frame
+// unless cfg.ocfg.reset (libsac.cpp:461-466), so a caller that encodes a file frame by frame gets the
+// reference's warm-started searches.  Callers that want many frames in one GPU batch use the C ABI's
+// sacamd_encode_frames directly.
 // Errors: the reference prints and continues or terminates; here every failure throws
 // std::runtime_error with sacamd_last_error() (never across the C ABI, which returns codes).
 #pragma once
@@ -33,9 +35,9 @@ class FrameCoder {
   };
   struct FrameStats { int maxbpn = 0, maxbpn_map = 0; bool enc_mapped = false; int32_t blocksize = 0, minval = 0, maxval = 0, mean = 0; };
 
-  FrameCoder(int numchannels, int framesize, const tsac_cfg &sac_cfg, int max_batch = 1, int device = 0)
-      : numchannels_(numchannels), framesize_(framesize), numsamples_(0), cfg(sac_cfg), max_batch_(max_batch) {
-    if (sacamd_ctx_create(device, numchannels, framesize, max_batch, &ctx_) != 0)
+  FrameCoder(int numchannels, int framesize, const tsac_cfg &sac_cfg, int device = 0)
+      : numchannels_(numchannels), framesize_(framesize), numsamples_(0), cfg(sac_cfg) {
+    if (sacamd_ctx_create(device, numchannels, framesize, 1, &ctx_) != 0)
       throw std::runtime_error("sacamd_ctx_create failed (no gfx950 device?)");
     samples.assign(numchannels, std::vector<int32_t>(framesize));
     error = s2u_error = pred = samples;
@@ -106,9 +108,10 @@ class FrameCoder {
     chk(sacamd_frames_upload_i32(ctx_, 1, framesize_, buf.data(), (long long)numchannels_ * numsamples_, numsamples_, &numsamples_));
   }
   void run_search_and_final(const sacamd_cfg &c) {
-    // FrameCoder::Predict (libsac.cpp:443-479): Optimize (the DDS search) -> base_profile, then the final pass
-    sacamd_default_profile(nullptr, nullptr, base_profile.data());
-    chk(sacamd_search_frames(ctx_, &c, base_profile.data()));
+    // FrameCoder::Predict (libsac.cpp:443-479): Optimize (the DDS search) -> base_profile, then the final pass.
+    // base_profile is the previous frame's optimum unless --opt-reset (libsac.cpp:461-466: LoadBaseProfile only
+    // `if (cfg.ocfg.reset)`; sacamd_search_frames ignores the input in that case); without optimize it is used as is.
+    if (c.optimize) chk(sacamd_search_frames(ctx_, &c, base_profile.data()));
     chk(sacamd_predict_final(ctx_, &c, base_profile.data()));
     int32_t st[8];
     chk(sacamd_get_stats(ctx_, st));
@@ -129,7 +132,6 @@ class FrameCoder {
   }
   int numchannels_, framesize_, numsamples_;
   tsac_cfg cfg;
-  int max_batch_;
   sacamd_ctx *ctx_ = nullptr;
   std::vector<int32_t> ferr_, fpred_, fs2u_;
   int maxbpn_[2] = {0, 0};

@@ -44,3 +44,11 @@ def golden_r2():
 
     path = os.path.join(ROOT, "tests", "golden", "ref_golden_r2.npz")
     return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden_r3():
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", "ref_golden_r3.npz")
+    return np.load(path, allow_pickle=False)

@@ -72,6 +72,24 @@ def main_r2():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def main_r3():
+    """tests/golden/ref_golden_r3.npz (round 3): warm-start chains (reset=0) of consecutive frames."""
+    from golden_cases import chain_cases
+    R = Checker("ref")
+    out = {}
+    for name, (frames, cfg) in chain_cases().items():
+        prof = None
+        for f, raw in enumerate(frames):
+            r = R.encode_frame(raw, cfg, FRAMESIZE, profile=prof)
+            prof = r["profile"]
+            out[f"chain/{name}/{f}/raw"] = raw.astype(np.int16)
+            out[f"chain/{name}/{f}/record"] = np.frombuffer(r["record"], np.uint8)
+            out[f"chain/{name}/{f}/profile"] = prof
+    path = os.path.join(HERE, "ref_golden_r3.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     R = Checker("ref")
     out = {}
@@ -153,5 +171,7 @@ if __name__ == "__main__":
         main_subframes()
     elif "--r2" in sys.argv:
         main_r2()
+    elif "--r3" in sys.argv:
+        main_r3()
     else:
         main()

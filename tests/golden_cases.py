@@ -76,6 +76,16 @@ def trace_cases_r2(P):
     return c
 
 
+def chain_cases():
+    """name -> (list of raw frames [nch,n], FrameCfg): consecutive frames of ONE file encoded with reset=0, the
+    reference's default: the best profile of frame f is the search start of frame f+1 AND the profile written for
+    frame f (libsac.cpp:461-466, :571)."""
+    c = {}
+    c["chain_s16_mt4"] = ([synth_pcm(4000, 2, 60 + f, RATE) for f in range(3)], frame_cfg("high", num_threads=4, maxnfunc=12, reset=0))
+    c["chain_m16_single"] = ([synth_pcm(3000, 1, 70 + f, RATE) for f in range(2)], frame_cfg("high", num_threads=0, maxnfunc=10, reset=0))
+    return c
+
+
 FULL_RATE = 44100
 FULL_FRAMESIZE = 20 * FULL_RATE
 

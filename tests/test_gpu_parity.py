@@ -6,7 +6,7 @@ bit-exact; fp64 intermediates within the tolerance written next to each assertio
 import numpy as np
 import pytest
 
-from golden_cases import (FRAMESIZE, FULL_FRAMESIZE, RATE, frame_cases, fullsize_cases, rand_profile, trace_cases,
+from golden_cases import (FRAMESIZE, FULL_FRAMESIZE, RATE, chain_cases, frame_cases, fullsize_cases, rand_profile, trace_cases,
                           trace_cases_r2)
 from oracle_api import center_frame, frame_cfg, ref_available
 from sac_amd.synth import synth_pcm
@@ -523,6 +523,32 @@ def test_framecoder_wrapper_writes_the_reference_records(api, golden, tmp_path):
         subprocess.run([exe, str(inp), str(nch), str(n), str(FRAMESIZE), str(cfg.optimize), repr(cfg.fraction), str(cfg.maxnfunc),
                         str(cfg.num_threads), repr(cfg.sigma), str(outp)], check=True)
         assert outp.read_bytes() == golden[f"frame/{name}/record"].tobytes(), name
+
+
+@pytest.mark.parametrize("name", list(chain_cases().keys()))
+def test_framecoder_wrapper_warm_start_chain(api, golden_r3, tmp_path, name):
+    """ONE sacamd::FrameCoder encoding the consecutive frames of a file with reset=0, the reference's default: every
+    search starts from the previous frame's optimum (libsac.cpp:461-466) -> all records equal the genuine reference's.
+    The same chain through the C ABI's batch entry point, one frame per call, profiles_io carried by the caller."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sac_amd", "framecoder_test")
+    frames, cfg = chain_cases()[name]
+    raws = [golden_r3[f"chain/{name}/{f}/raw"].astype(np.int32) for f in range(len(frames))]
+    want = [golden_r3[f"chain/{name}/{f}/record"].tobytes() for f in range(len(frames))]
+    nch, n = raws[0].shape
+    inp = tmp_path / f"{name}.i32"; outp = tmp_path / f"{name}.rec"
+    np.ascontiguousarray(np.stack(raws), np.int32).tofile(inp)
+    subprocess.run([exe, str(inp), str(nch), str(n), str(FRAMESIZE), str(cfg.optimize), repr(cfg.fraction), str(cfg.maxnfunc),
+                    str(cfg.num_threads), repr(cfg.sigma), str(outp), "0", str(len(raws))], check=True)
+    assert outp.read_bytes() == b"".join(want), name
+    ctx = api.Context(nch, FRAMESIZE, 1)
+    prof = None
+    for f, raw in enumerate(raws):
+        ctx.upload_i32([raw], FRAMESIZE)
+        recs, prof = ctx.encode_frames(gpu_cfg(api, cfg), profiles=prof)
+        assert recs[0] == want[f], (name, f)
+        assert np.array_equal(prof[0], golden_r3[f"chain/{name}/{f}/profile"])
+    ctx.close()
 
 
 @pytest.mark.parametrize("env", [{"SACAMD_CHASE": "1"}, {"SACAMD_TAIL_HI": "1"}, {"SACAMD_TAIL_HI": "1", "SACAMD_TAIL_PRIO": "1"}])

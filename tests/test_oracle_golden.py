@@ -5,7 +5,7 @@ import zlib
 import numpy as np
 import pytest
 
-from golden_cases import FRAMESIZE, frame_cases, trace_cases, trace_cases_r2
+from golden_cases import FRAMESIZE, chain_cases, frame_cases, trace_cases, trace_cases_r2
 from oracle_api import center_frame
 
 
@@ -140,3 +140,16 @@ def test_subframe_plan_matches_reference(orc, name):
     for ch in range(pcm.shape[0]):
         used, cost = orc.sparse_cost(pcm[ch, :blk])
         assert (used, cost) == tuple(g[f"{name}/cost_block0"][ch])        # bit-exact doubles
+
+
+@pytest.mark.parametrize("name", list(chain_cases().keys()))
+def test_warm_start_chain_vs_golden(orc, golden_r3, name):
+    """reset=0 (the reference's default): frame f+1's search starts from frame f's optimum (libsac.cpp:461-466)."""
+    frames, cfg = chain_cases()[name]
+    prof = None
+    for f in range(len(frames)):
+        raw = golden_r3[f"chain/{name}/{f}/raw"].astype(np.int32)
+        r = orc.encode_frame(raw, cfg, FRAMESIZE, profile=prof)
+        prof = r["profile"]
+        assert r["record"] == golden_r3[f"chain/{name}/{f}/record"].tobytes(), (name, f)
+        assert np.array_equal(prof, golden_r3[f"chain/{name}/{f}/profile"])
