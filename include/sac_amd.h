@@ -172,9 +172,10 @@ int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
 /* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*8 + class)*4 + {0,1,2,3}] =
  * total ms (HIP events on the launch's stream), launches, item-steps processed, algorithmic fp64 flops (FMA = 2,
  * SURVEY.md 8d formula with each item's actual regressor length / tap counts); kind 0 = OLS capacity
- * classes 0..7 (16,24,32 taps: k_ols<64,NMAX>; 40..96: k_ols<256,NMAX>), kind 1 = cascade layout classes 0..11
- * (0..6: search layouts, 7..9: canonical-order layouts of the final pass).  out has (8 + 12) * 4 = 80 entries. */
-int sacamd_class_times(sacamd_ctx *ctx, double *out80, int reset);
+ * classes 0..7 (16,24,32 taps: k_ols<64,NMAX>; 40..96: k_ols<256,NMAX>), kind 1 = cascade layout classes 0..15
+ * (0..6: search layouts, 7..9 and 10..13: canonical-order layouts of the final pass).  out receives (8 + 16) * 4 = 96
+ * entries; cap = capacity of out in doubles (SACAMD_ERR_ARG if smaller).  ABI version 2 (version 1 had no cap and 80 entries). */
+int sacamd_class_times(sacamd_ctx *ctx, double *out96, int cap, int reset);
 
 /* Progress of a running sacamd_encode_frames on this context; may be called from another thread while that call
  * is in flight (the only entry point that may).  phase: 0 idle, 1 DDS search, 2 final prediction pass, 3 entropy

@@ -62,6 +62,9 @@ def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, f
 _lib = None
 
 
+ABI_VERSION = 2
+
+
 def load_library():
     global _lib
     if _lib is None:
@@ -71,6 +74,9 @@ def load_library():
         _lib.sacamd_last_error.restype = c_char_p
         _lib.sacamd_last_error.argtypes = [c_void_p]
         _lib.sacamd_ctx_destroy.argtypes = [c_void_p]
+        if _lib.sacamd_abi_version() != ABI_VERSION:
+            v = _lib.sacamd_abi_version(); _lib = None
+            raise SacAmdError(f"{LIB_PATH} has ABI version {v}, this binding needs {ABI_VERSION}: rebuild (make -C sac_amd/csrc)")
     return _lib
 
 
@@ -309,11 +315,11 @@ class Context:
 
     def class_times(self, reset=True):
         """per kernel instance: {(kind, class): (ms, launches, item_steps, fp64 flops)}, kind 'ols' | 'lms'."""
-        out = np.zeros(80)
-        self._chk(self.lib.sacamd_class_times(self.h, _vp(out), int(reset)))
-        o = out.reshape(20, 4)
+        out = np.zeros(96)
+        self._chk(self.lib.sacamd_class_times(self.h, _vp(out), out.size, int(reset)))
+        o = out.reshape(24, 4)
         res = {("ols", c): tuple(o[c]) for c in range(8) if o[c, 1] > 0}
-        res.update({("lms", c): tuple(o[8 + c]) for c in range(12) if o[8 + c, 1] > 0})
+        res.update({("lms", c): tuple(o[8 + c]) for c in range(16) if o[8 + c, 1] > 0})
         return res
 
     def progress(self):

@@ -171,7 +171,7 @@ struct sacamd_ctx {
   std::vector<TraceSpan> trace;
   bool tracing = false;
   // [kind 0 = OLS classes 0..7, kind 1 = cascade classes 0..2][class] -> ms, launches, item-steps
-  static constexpr int kClsMax = 12;   // >= kNumOlsClasses, kNumLmsClasses
+  static constexpr int kClsMax = 16;   // >= kNumOlsClasses, kNumLmsClasses
   double cls_ms[2][kClsMax] = {}, cls_item_steps[2][kClsMax] = {}, cls_flops[2][kClsMax] = {};
   // progress of sacamd_encode_frames, readable from another thread (sacamd_progress): phase 0 idle, 1 search,
   // 2 final prediction pass, 3 entropy coding; generation = DDS generations evaluated so far
@@ -346,7 +346,7 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
       it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab; it.off_tabc = -1;
       off_p += cd.n;
       for (int s = 0; s < 4; s++) off_tab += 2LL * vn[s];
-      if (it.lms_class >= kLmsCanonFirst) { it.off_tabc = off_tab; off_tab += canon_tab_doubles(canon_rounds_of_class(it.lms_class)); }
+      if (it.lms_class >= kLmsCanonFirst && it.lms_class < kLmsCanon3First) { it.off_tabc = off_tab; off_tab += canon_tab_doubles(canon_rounds_of_class(it.lms_class)); }
       items.push_back(it);
     }
   }
@@ -654,7 +654,7 @@ void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start
 }  // namespace
 
 // ================================================================== context
-API int sacamd_abi_version(void) { return 1; }
+API int sacamd_abi_version(void) { return 2; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes
 
 API void sacamd_default_cfg(sacamd_cfg *cfg) {
   std::memset(cfg, 0, sizeof(*cfg));
@@ -1140,8 +1140,8 @@ API int sacamd_eval_stats(sacamd_ctx *c, long long *out2, int reset) {
   return 0;
 }
 
-API int sacamd_class_times(sacamd_ctx *c, double *out, int reset) {
-  if (!c || !out) return SACAMD_ERR_ARG;
+API int sacamd_class_times(sacamd_ctx *c, double *out, int cap, int reset) {
+  if (!c || !out || cap < (kNumOlsClasses + sacamd_ctx::kClsMax) * 4) return SACAMD_ERR_ARG;
   collect_spans(c);
   static_assert(kNumOlsClasses == 8 && kNumLmsClasses <= sacamd_ctx::kClsMax, "sacamd_class_times layout");
   for (int kind = 0; kind < 2; kind++)

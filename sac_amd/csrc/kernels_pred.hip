@@ -7,6 +7,7 @@
 #include "pred_tables.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace sacamd {
 
@@ -139,7 +140,13 @@ using LmsL = LmsClass<17, 9, 5, 3>;
 // the tables in LDS (mode 1, 27 instead of 9 bytes per tap) only one workgroup fits a CU from ~4000 taps on and launches
 // had to be cut wherever the combined ring sizes of their items exceeded the LDS -- 56 launches serialised on four
 // streams in the 384 x 20 s run.  Measured per-step time is the same in both modes.
-constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : 2; }
+constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : (cls < kLmsCanon3First ? 2 : 3); }
+// Lane-map canonical layouts (pred_lms.h, CANON 3): LmsClass<J,0,0,0> = J chain positions per lane; 256 lanes = 2 dot + 2
+// power-sum waves, 512 lanes = 4 + 4.  An item takes the first of these its chains fit (canon3_fits); what fits none of them
+// (more than ~7.5 k taps) falls back to the systolic four-round layout 9.
+using LmsP17 = LmsClass<17, 0, 0, 0>;
+using LmsP33 = LmsClass<33, 0, 0, 0>;
+using LmsP49 = LmsClass<49, 0, 0, 0>;
 template <int CLS> struct LmsCfg;
 template <> struct LmsCfg<0> { static constexpr int ROUNDS = 1; using C = LmsA; static constexpr int NL = 256, MINB = 1; };
 template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 256, MINB = 2; };
@@ -151,6 +158,10 @@ template <> struct LmsCfg<6> { static constexpr int ROUNDS = 1; using C = LmsY; 
 template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
 template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
 template <> struct LmsCfg<9> { using C = LmsK; static constexpr int NL = 256, MINB = 1, ROUNDS = 4; };
+template <> struct LmsCfg<10> { using C = LmsP17; static constexpr int NL = 256, MINB = 3, ROUNDS = 1; };
+template <> struct LmsCfg<11> { using C = LmsP33; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
+template <> struct LmsCfg<12> { using C = LmsP49; static constexpr int NL = 256, MINB = 1, ROUNDS = 1; };
+template <> struct LmsCfg<13> { using C = LmsP33; static constexpr int NL = 512, MINB = 2, ROUNDS = 1; };
 
 template <int CLS>
 __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf, LmsRingCap rc) {
@@ -176,7 +187,7 @@ static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_id
   static std::atomic<unsigned long long> done{0};
   constexpr int CANON = lms_canon_mode(CLS);
   constexpr size_t kLdsPerCu = 160 * 1024;     // a layout's register capacity may exceed what one CU's LDS can hold as history
-  const size_t full = LmsLds<NL, C, CANON>::bytes();
+  const size_t full = CANON == 3 ? kLdsPerCu : LmsLds<NL, C, CANON>::bytes();
   if (ensure_dyn_lds((const void *)k_lms<CLS>, full < kLdsPerCu ? full : kLdsPerCu, done) != hipSuccess) return;
   const size_t bytes = LmsLds<NL, C, CANON>::bytes(rc.c);
   hipLaunchKernelGGL((k_lms<CLS>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_tab, d_p, d_q, rc);
@@ -193,6 +204,10 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 7: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     case 8: return LmsLds<256, LmsK, 2>::bytes(rc.c);
     case 9: return LmsLds<256, LmsK, 2>::bytes(rc.c);
+    case 10: return LmsLds<256, LmsP17, 3>::bytes(rc.c);
+    case 11: return LmsLds<256, LmsP33, 3>::bytes(rc.c);
+    case 12: return LmsLds<256, LmsP49, 3>::bytes(rc.c);
+    case 13: return LmsLds<512, LmsP33, 3>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
   }
 }
@@ -201,6 +216,13 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
 int lms_class_for(const int *vn, bool canon) {
   auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
   if (canon) {
+    static const bool old_layouts = [] { const char *e = std::getenv("SACAMD_CANON_SYSTOLIC"); return e && e[0] == '1'; }();   // A/B switch: the round-2 layouts
+    if (!old_layouts) {
+      if (canon3_fits(vn, LmsP17::c0, 2)) return 10;
+      if (canon3_fits(vn, LmsP33::c0, 2)) return 11;
+      if (canon3_fits(vn, LmsP49::c0, 2)) return 12;
+      if (canon3_fits(vn, LmsP33::c0, 4)) return 13;
+    }
     if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 7;     // one round over the lanes
     if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 8;     // two rounds
     return 9;                                                            // four rounds (profile maximum)
@@ -215,7 +237,10 @@ int lms_class_for(const int *vn, bool canon) {
 }
 
 // register-file bound on resident workgroups per CU (237 / 256 / 256 registers, 4 / 4 / 8 waves)
-int lms_max_wg_per_cu(int lms_class) { return (lms_class == 2 || lms_class == 9) ? 1 : 2; }
+int lms_max_wg_per_cu(int lms_class) {
+  if (lms_class == 10) return 3;
+  return (lms_class == 2 || lms_class == 9 || lms_class == 12 || lms_class == 13) ? 1 : 2;
+}
 
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, const double *d_p, double *d_q) {
@@ -230,6 +255,10 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 7: launch_lms_c<7>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 8: launch_lms_c<8>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 9: launch_lms_c<9>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 10: launch_lms_c<10>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 11: launch_lms_c<11>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 12: launch_lms_c<12>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 13: launch_lms_c<13>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     default: launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
   }
 }

@@ -17,8 +17,9 @@ constexpr int kStages = 4;
 // regressor-length capacity of each OLS kernel instance; the last one is the two-wave generic path
 constexpr int kNumOlsClasses = 8;
 constexpr int kOlsClassMax[kNumOlsClasses] = {16, 24, 32, 40, 48, 56, 64, 96};
-constexpr int kNumLmsClasses = 10;   // 0..6 search layouts (free summation order), 7..9 canonical-order layouts of the final pass
+constexpr int kNumLmsClasses = 14;   // 0..6 search layouts (free summation order), 7..9 canonical-order layouts (systolic, stage by stage), 10..13 lane-map canonical layouts (final pass)
 constexpr int kLmsCanonFirst = 7;
+constexpr int kLmsCanon3First = 10;   // lane-map canonical layouts (no lane-major table copies: off_tabc stays -1)
 
 struct ChanParam {
   // OLS

@@ -55,6 +55,57 @@ SA_HD void static_for(F &&f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
+// ---- CANON 3: lane-map layout of the canonical-order sums (round 3) ----
+// All 48 summation chains of a sample (4 stages x (8 dot + 4 power-sum chains)) run AT THE SAME TIME, each on a run of
+// adjacent lanes of one wave: a chain of K positions owns g = ceil(K / J) lanes, lane m of the run holds positions
+// mJ .. mJ+J-1 (weights resp. powtab in registers for the whole frame, history values loaded once per sample) and the
+// running sum hops from lane to lane (DPP wave_shr:1) exactly as in the older layouts.  Because lanes are handed out
+// in proportion to chain length, every wave finishes after about max(K) dependent FMAs, and one FMA instruction
+// carries 64 / g chains instead of the two (of one stage) the older layouts gave it.  Waves are homogeneous: the
+// first D waves of the workgroup hold dot chains (they also update the weights), the other D hold power-sum chains.
+// The lane -> (stage, chain, block) map depends on the item's stage lengths and is computed by every lane at start-up
+// (canon3_pack: chains sorted by lane count, first fit into the waves of their kind; a chain never straddles a wave).
+struct Canon3Lane { int st, ch, m, g; bool act; };
+// kind 0 = dot chains (stride 8; at least one lane per chain: its first lane also owns the chain's tail tap),
+// kind 1 = power-sum chains (stride 4).  q = lane index within the kind (0 .. 64*D-1) or -1 (fit test only).
+// Returns false when the chains do not fit D waves of 64 lanes with J positions per lane.
+SA_HD bool canon3_pack(const int *vn, int J, int D, int kind, int q, Canon3Lane *out, int *gmax) {
+  int g[4], order[4] = {0, 1, 2, 3};
+  for (int s = 0; s < 4; s++) {
+    const int K = vn[s] >= 8 ? (kind ? vn[s] >> 2 : vn[s] >> 3) : 0;
+    g[s] = (K + J - 1) / J;
+    if (!kind && g[s] < 1) g[s] = 1;
+    if (g[s] > 64) return false;
+  }
+  for (int a = 1; a < 4; a++)              // insertion sort, stable, longest first
+    for (int b = a; b > 0 && g[order[b]] > g[order[b - 1]]; b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out) { out->st = 0; out->ch = 0; out->m = 0; out->g = 0; out->act = false; }
+  int gm = 0;
+  const int nchain = kind ? 4 : 8;
+  for (int a = 0; a < 4; a++) {
+    const int s = order[a];
+    if (!g[s]) continue;
+    gm = g[s] > gm ? g[s] : gm;
+    for (int c = 0; c < nchain; c++) {
+      int w = 0;
+      while (w < D && fill[w] + g[s] > 64) w++;
+      if (w == D) return false;
+      const int first = 64 * w + fill[w];
+      if (out && q >= first && q < first + g[s]) { out->st = s; out->ch = c; out->m = q - first; out->g = g[s]; out->act = true; }
+      fill[w] += g[s];
+    }
+  }
+  if (gmax) *gmax = gm;
+  return true;
+}
+SA_HD bool canon3_fits(const int *vn, int J, int D) {
+  return canon3_pack(vn, J, D, 0, -1, nullptr, nullptr) && canon3_pack(vn, J, D, 1, -1, nullptr, nullptr);
+}
+// history rings of the lane-map layout: capacity >= 8J+8 and the first 8J+8 elements mirrored behind the end, so that a
+// lane's window of J positions (stride 8 or 4) never wraps: one base address per lane and sample, immediate offsets
+SA_HD constexpr int canon3_ext(int J) { return 8 * J + 8; }
+
 // P-row dot of the RLS stage with a run-time order 1..10 but compile-time unrolling
 template <class A, class B>
 SA_HD double dot_canon_m(int m, A a, B b) {
@@ -71,6 +122,9 @@ SA_HD double dot_canon_m(int m, A a, B b) {
 template <int NL, class C, int CANON = 0>
 struct LmsLds {
   SA_HD static constexpr int ridx(int a) { return CANON ? a + (a >> 3) : a; }   // physical ring index
+  // CANON 3: logical ring length for a capacity request c (>= taps + 1): capacity raised to the mirror length, plus the mirror
+  SA_HD static constexpr int ringcap3(int c) { return c > canon3_ext(C::c0) ? c : canon3_ext(C::c0); }
+  SA_HD static constexpr int ringlen(int c) { return CANON == 3 ? ringcap3(c) + canon3_ext(C::c0) : c; }
   double *csum, *psum, *tailw, *tailpw;   // CANON: chain sums [2][4][8], [2][4][4]; tail weights [2][4][8]; tail powtab [4][8]
   double *mt[4], *pt[4];                  // CANON: mutab / powtab of each stage, indexed like the rings (ridx(tap)); read once per sample
   double *ring[4];
@@ -90,8 +144,9 @@ struct LmsLds {
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
     #pragma unroll
-    for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringcap[s]) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
+    for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringlen(ringcap[s])) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
     if (CANON) d += 64 + 32 + 64 + 32;
+    if (CANON == 3) d += (size_t)(NL / 2) * C::c0;     // mutab of the dot lanes, lane-major per wave
     d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + NL * sizeof(int) + 16;
   }
@@ -108,9 +163,10 @@ struct LmsLds {
       csum = d; d += 64; psum = d; d += 32; tailw = d; d += 64; tailpw = d; d += 32;
     }
     #pragma unroll
-    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ridx(ringcap[s]) + 1; }
+    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ridx(ringlen(ringcap[s])) + 1; }
     #pragma unroll
     for (int s = 0; s < 4; s++) { mt[s] = pt[s] = nullptr; if (CANON == 1) { mt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; pt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; } }
+    if (CANON == 3) { mt[0] = d; d += (size_t)(NL / 2) * C::c0; }
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 8;
     pin = d; d += NL; pout = d; d += NL;
@@ -168,6 +224,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // CANON geometry: the 8 dot chains are spread CPW per wave over LPC lanes each; the 4 power-sum chains
   // run on waves 0..3, 64 lanes each, with SMUL times the slots per lane
   static_assert(!CANON || NL == 256 || NL == 512, "canonical layout: 4 or 8 waves");
+  constexpr bool LM = CANON == 3;                 // lane-map layout (canon3_pack)
+  constexpr int J3 = LM ? C::c0 : 1, D3 = NL / 128, EXT3 = canon3_ext(J3);
   // ROUNDS: a chain passes ROUNDS times over its lanes (positions r*LPC*J + m*J + j); the weights of all rounds stay in
   // registers, the chain operands of one round at a time.  The power-sum chains (twice the positions, twice the lanes
   // when NL = 256) make ROUNDS * SMUL rounds.
@@ -179,14 +237,19 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   typename E::template Reg<DArr<CANON ? 1 : C::total>> MT, PT;   // CANON: the tables stay in LDS (read once per sample): the chain operands need the registers
   typename E::template Reg<DArr<NX>> PR;                 // CANON: powtab of this lane's power-chain taps, loaded for the duration of the chains
   typename E::template Reg<DArr<8>> acc;
-  typename E::template Reg<DArr<CANON ? 4 : 1>> Wt;        // CANON: the chain's tail tap (taps beyond 8*floor(n/8)) of lanes m == 0
+  typename E::template Reg<DArr<(CANON && !LM) ? 4 : 1>> Wt;        // CANON: the chain's tail tap (taps beyond 8*floor(n/8)) of lanes m == 0
+  // lane-map layout: W = weights (dot lanes) resp. powtab (power lanes), XD = this sample's history values resp. squares
+  typename E::template Reg<int> q_pos, q_cap, q_tap0, q_ro, q_sc, q_fl, q_ttap;   // ring position / capacity / first tap / ring offset / stage*8+chain / flags / tail tap
+  typename E::template Reg<double> q_acc, q_mut;                                   // running chain sum; mutab of the tail tap
+  int G3d = 0, G3p = 0;                                                           // hops of the dot / power waves
   typename E::template Reg<DArr<NX>> XD;                        // CANON: history values of this lane's dot-chain taps
   typename E::template Reg<DArr<NX>> XX;                 // CANON: squared history values of this lane's power-chain taps
   typename E::template Reg<double> sd[4], sq[4], hop;           // CANON: running chain sums
 
   int ns[4], cap[4], pos[4];
   #pragma unroll
-  for (int s = 0; s < 4; s++) { ns[s] = p.vn[s]; cap[s] = ns[s] + 1; pos[s] = 0; }
+  for (int s = 0; s < 4; s++) { ns[s] = p.vn[s]; cap[s] = ns[s] + 1; pos[s] = 0; if (LM && cap[s] < EXT3) cap[s] = EXT3; }
+  if constexpr (LM) { canon3_pack(ns, J3, D3, 0, -1, nullptr, &G3d); canon3_pack(ns, J3, D3, 1, -1, nullptr, &G3p); }
   const int m = p.lm_n;
 
   // ---- init: tables -> registers, zero rings / weights
@@ -213,6 +276,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           MT[l].v[f + j] = on ? tp[tap] : 0.0;
           PT[l].v[f + j] = on ? tp[ns[s] + tap] : 0.0;
         }
+      } else if constexpr (LM) {
+        if (l < 8) { const int K4 = ns[s] >= 8 ? ns[s] >> 2 : 0; const int ti = 4 * K4 + l; L.tailpw[s * 8 + l] = ti < ns[s] ? tp[ns[s] + ti] : 0.0; }
       } else {
         // dot layout: lane (wave w, half, m) owns positions m*J..m*J+J-1 of chain c = w*CPW + half, i.e. taps 8k + c;
         // positions >= K8 = n/8 are empty.  The chain's tail tap 8*K8 + c (if < n) sits in the extra slot of lane m == 0.
@@ -223,7 +288,39 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         if (l < 8) { const int ti = 4 * K4 + l; L.tailpw[s * 8 + l] = ti < ns[s] ? tp[ns[s] + ti] : 0.0; }
       }
       tp += 2 * ns[s];
-      for (int i = l; i <= ridx(cap[s]); i += NL) L.ring[s][i] = 0.0;
+      for (int i = l; i <= ridx(LM ? cap[s] + EXT3 : cap[s]); i += NL) L.ring[s][i] = 0.0;
+    }
+    if constexpr (LM) {
+      // this lane's run of chain positions (canon3_pack) and its static operands
+      const bool dotl = l < 64 * D3;
+      Canon3Lane cl;
+      canon3_pack(ns, J3, D3, dotl ? 0 : 1, dotl ? l : l - 64 * D3, &cl, nullptr);
+      const int st = cl.st, stride = dotl ? 8 : 4;
+      const int nst = ns[st], K = nst >= 8 ? (dotl ? nst >> 3 : nst >> 2) : 0;
+      const double *tps = tab;
+      for (int s = 0; s < st; s++) tps += 2 * ns[s];
+      int ro = 0;
+      for (int s = 0; s < st; s++) ro += (int)(L.ring[s + 1] - L.ring[s]);
+      q_ro[l] = ro; q_cap[l] = cap[st]; q_pos[l] = 0; q_sc[l] = st * 8 + cl.ch;
+      q_tap0[l] = cl.act ? stride * (cl.m * J3) + cl.ch : 0;
+      q_fl[l] = (cl.act && cl.m == 0 ? 1 : 0) | (cl.act && cl.m == cl.g - 1 ? 2 : 0) | (cl.act ? 4 : 0) | (cl.act ? 0 : 1);   // unassigned lanes start a (dead) chain of their own
+      q_acc[l] = 0.0; q_mut[l] = 0.0; q_ttap[l] = 0;
+      double *mtl = L.mt[0] + (size_t)((l >> 6) * J3) * 64 + (l & 63);
+#pragma unroll
+      for (int j = 0; j < J3; j++) {
+        const int k = cl.m * J3 + j, tap = stride * k + cl.ch;
+        const bool on = cl.act && k < K;
+        if (dotl) { W[l].v[j] = 0.0; mtl[j * 64] = on ? tps[tap] : 0.0; }
+        else W[l].v[j] = on ? tps[nst + tap] : 0.0;          // powtab; positions beyond the chain are empty
+        XD[l].v[j] = 0.0;
+      }
+      if (dotl) {    // the chain's tail tap 8*K8 + c: owned by the chain's first lane
+        const int tt = 8 * K + cl.ch;
+        Wt[l].v[0] = 0.0;
+        const bool on = cl.act && cl.m == 0 && tt < nst;
+        q_mut[l] = on ? tps[tt] : 0.0;
+        q_ttap[l] = tt < nst - 1 ? tt : nst - 1;
+      }
     }
     if (l < 8) { L.bc[l] = 0.0; L.pv[l] = 0.0; }
     sa_stage_tables(L.libm, l, NL);
@@ -332,6 +429,70 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           dst[0] = acc[l].v[0]; dst[1] = acc[l].v[1];
         }
       });
+      } else if constexpr (LM) {
+      // Lane-map layout: one parallel phase (history loads, weight update of the dot lanes, squares of the power lanes),
+      // then all chains hop along their lane runs at once.
+      ex.par([&](int l) {
+        const bool dotl = l < 64 * D3;
+        int u0 = q_pos[l] + q_tap0[l]; if (u0 >= q_cap[l]) u0 -= q_cap[l];
+        const double *rg = L.ring[0] + q_ro[l];
+        if (dotl) {
+          // positions k0 + j -> taps 8 (k0 + j) + c: padded ring index ridx(u0 + 8j) = ridx(u0) + 9j (no wrap: mirrored ring)
+          const int bn = ridx(u0), bo = ridx(u0 + 1);
+          const int st = q_sc[l] >> 3;
+          const double wg = L.bc[st];
+          const double *mtl = L.mt[0] + (size_t)((l >> 6) * J3) * 64 + (l & 63);
+#pragma unroll
+          for (int j = 0; j < J3; j++) {
+            const double xn = rg[bn + 9 * j], xo = rg[bo + 9 * j];
+            double w = fma(mtl[j * 64], wg * xo, W[l].v[j]);       // mutab is 0 at empty positions: the weight stays 0
+            w = clampd(w, -10.0, 10.0);
+            W[l].v[j] = w;
+            XD[l].v[j] = xn;
+          }
+          {   // the chain's tail tap (first lane of the chain; elsewhere its mutab is 0)
+            int in = q_pos[l] + q_ttap[l]; if (in >= q_cap[l]) in -= q_cap[l];
+            const double xo = rg[ridx(in + 1)];
+            double w = fma(q_mut[l], wg * xo, Wt[l].v[0]);
+            w = clampd(w, -10.0, 10.0);
+            Wt[l].v[0] = w;
+            if ((q_fl[l] & 5) == 5) L.tailw[(par * 4 + st) * 8 + (q_sc[l] & 7)] = w;
+          }
+        } else {
+          // taps 4 (k0 + j) + c4: even j at ridx(u0) + 9 (j/2), odd j at ridx(u0 + 4) + 9 (j/2)
+          const int be = ridx(u0), bd = ridx(u0 + 4);
+#pragma unroll
+          for (int j = 0; j < J3; j++) {
+            const double xs = rg[((j & 1) ? bd : be) + 9 * (j >> 1)];
+            XD[l].v[j] = xs * xs;
+          }
+        }
+        q_acc[l] = 0.0;
+      });
+      SA_TICK(0);
+      {
+        const int G = ex.wave_hops(64 * D3, G3d, G3p);
+        for (int h = 0; h < G; h += 2) {
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            typename E::template Reg<double> sh = q_acc;
+            ex.shift_up1(sh);
+            ex.par([&](int l) {
+              double a = (q_fl[l] & 1) ? 0.0 : sh[l];
+#pragma unroll
+              for (int j = 0; j < J3; j++) a = fma(XD[l].v[j], W[l].v[j], a);
+              q_acc[l] = a;
+            });
+          }
+        }
+      }
+      ex.par([&](int l) {
+        if ((q_fl[l] & 6) == 6) {
+          if (l < 64 * D3) L.csum[(par * 4 + (q_sc[l] >> 3)) * 8 + (q_sc[l] & 7)] = q_acc[l];
+          else L.psum[(par * 4 + (q_sc[l] >> 3)) * 4 + (q_sc[l] & 7)] = q_acc[l];
+        }
+      });
+      SA_TICK(1);
       } else {
       // Canonical order (slmath::dot / calc_s2pow): weight update of this lane's chain positions, then the
       // running sums hop along the lanes of each chain.  After hop h the sum held by lane m <= h is final, so
@@ -663,7 +824,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
           int np = ps - 1; if (np < 0) np += cs;
           rg[ridx(np)] = bps;
-          if (np == 0) rg[ridx(cs)] = bps;        // mirror: ring[in + 1] needs no wrap in the sweep
+          if (LM ? np < EXT3 : np == 0) rg[ridx(cs + np)] = bps;        // mirror: ring[in + 1] (lane-map layout: a lane's whole window) needs no wrap in the sweep
         }
       });
       SA_TICK(4);
@@ -672,6 +833,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       have_prev = true;
       #pragma unroll
       for (int s = 0; s < 4; s++) { pos[s] -= 1; if (pos[s] < 0) pos[s] += cap[s]; }
+      if constexpr (LM) ex.par([&](int l) { int q = q_pos[l] - 1; if (q < 0) q += q_cap[l]; q_pos[l] = q; });
       SA_TICK(6);
       SA_TICK(7);
     }

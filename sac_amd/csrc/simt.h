@@ -76,6 +76,9 @@ struct ExecEmu {
   int lane_geti(const Reg<int> &r, int k) { return r[k]; }
   // every lane takes the value of lane-1 (lane 0 keeps its own): DPP wave_shr:1 on the device
   void shift_up1(Reg<double> &r) { for (int l = NL - 1; l > 0; l--) r[l] = r[l - 1]; }
+  // trip count of a loop whose length differs between the waves of a workgroup: lanes < split run a iterations, the others
+  // b (device: the calling wave's own count, wave-uniform; the emulator runs the lanes of all waves in one loop)
+  int wave_hops(int, int a, int b) { return a > b ? a : b; }
   // code only lane 0 executes: run once
   template <class F> void lane0(F &&f) { f(); }
   static unsigned long long clock() { return 0; }
@@ -199,6 +202,7 @@ struct ExecDev {
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
     r.v = __hiloint2double(hi, lo);
   }
+  SA_D int wave_hops(int split, int a, int b) { return __builtin_amdgcn_readfirstlane((int)threadIdx.x < split ? a : b); }
   template <class F> SA_D void lane0(F &&f) { if (threadIdx.x == 0) f(); }
   static SA_D unsigned long long clock() { return __builtin_readcyclecounter(); }
   static SA_D bool is_lane0() { return threadIdx.x == 0; }

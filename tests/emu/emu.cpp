@@ -68,7 +68,12 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     }
     for (int t = 0; t < n; t++) ps[t] = pl[t];
     const int *vn = p.vn;
-    if (!optimize) {   // as the launcher (lms_class_for): the final pass sums in slmath::dot order
+    const bool systolic = std::getenv("SACAMD_CANON_SYSTOLIC") && std::getenv("SACAMD_CANON_SYSTOLIC")[0] == '1';
+    if (!optimize && !systolic && canon3_fits(vn, 17, 2)) run_lms<LmsClass<17, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);       // as the launcher (lms_class_for): lane-map canonical layouts
+    else if (!optimize && !systolic && canon3_fits(vn, 33, 2)) run_lms<LmsClass<33, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);
+    else if (!optimize && !systolic && canon3_fits(vn, 49, 2)) run_lms<LmsClass<49, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);
+    else if (!optimize && !systolic && canon3_fits(vn, 33, 4)) run_lms<LmsClass<33, 0, 0, 0>, 512, 3>(p, sp, tab.data(), self, n, ps);
+    else if (!optimize) {   // the systolic layouts of round 2: fallback for the largest profiles; the final pass sums in slmath::dot order
       // lane-major table copies as k_tables writes them for the canonical layouts (pred_tables.h)
       const int rounds = (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256) ? 1 : ((vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) ? 2 : 4);
       std::vector<double> tabc((size_t)canon_tab_doubles(rounds), std::nan(""));
@@ -97,6 +102,16 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     bias_stage(p, self, n, ps, stats[3 * ch_self + 2], err + (size_t)ch_self * n, pred ? pred + (size_t)ch_self * n : nullptr, tables.data());
   }
   return 0;
+}
+
+// cascade layout class the launcher picks for the final pass of an item with these stage lengths (kernels_pred.hip,
+// lms_class_for): 10..13 = lane-map layouts (J, lanes) = (17,256) (33,256) (49,256) (33,512); 9 = systolic fallback
+API int emu_canon_class(const int *vn) {
+  if (canon3_fits(vn, 17, 2)) return 10;
+  if (canon3_fits(vn, 33, 2)) return 11;
+  if (canon3_fits(vn, 49, 2)) return 12;
+  if (canon3_fits(vn, 33, 4)) return 13;
+  return 9;
 }
 
 // ---------------------------------------------------------------- coder

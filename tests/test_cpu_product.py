@@ -38,7 +38,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     import sac_amd.api as api
     assert sorted(api.ABI_SYMBOLS) == declared
-    assert lib.sacamd_abi_version() == 1
+    assert lib.sacamd_abi_version() == 2
     # without a GPU the context constructor must fail loudly (no CPU fallback)
     import torch
     if not torch.cuda.is_available():
