@@ -377,6 +377,9 @@ std::vector<int> xcd_interleave(const std::vector<int> &v, const std::vector<Wor
   for (int i : v) b[items[i].frame % kXcds].push_back(i);
   size_t len = 0;
   for (auto &q : b) len = std::max(len, q.size());
+  // Only when the launch spans all eight residue classes about evenly: with few staged frames (the FrameCoder wrapper
+  // stages one) the arrangement would put all work on some XCDs and only padding workgroups on the others.
+  if (len * kXcds * 4 > v.size() * 5) return v;             // longest class > 1.25 x the mean
   std::vector<int> out;
   out.reserve(len * kXcds);
   for (size_t r = 0; r < len; r++)
@@ -549,7 +552,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     {
       double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
       Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
-      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p);
+      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, want_pred);
     }
     HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
     HIPCHK(c, hipStreamWaitEvent(c->cls_stream[kMark], c->ev_ols[k], 0));
@@ -1007,7 +1010,7 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
   for (int i = 0; i < count; i++) {
     HIPCHK(c, hipMemcpyAsync(c->d_idx.p, &i, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    { Span sp(c, FAM_OLS); launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p); }
+    { Span sp(c, FAM_OLS); launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p, !optimize); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (plpc) HIPCHK(c, hipMemcpy(plpc + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
     { Span sp(c, FAM_LMS);

@@ -27,7 +27,7 @@ void launch_analyse_i32(hipStream_t s, int nframes, int nch, const int *d_raw, l
                         FrameStatsD *d_stats, unsigned char *d_used);
 // ---- predictor stages (kernels_pred.hip)
 void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab);
-void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p);
+void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p, bool latency_bound);
 struct LmsRingCap { int c[4]; };   // per-stage history ring capacity (doubles) of one launch
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc);
 int lms_class_for(const int *vn, bool canon);   // cascade layout class for stage lengths vn[4]; canon: slmath::dot summation order (final pass)

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   double *out = (it.pin_kept ? v.keep : pbuf) + it.off_pin;   // off_pin: where this item's p_lpc lives
   int *prog = v.progress ? v.progress + idx[blockIdx.x] : nullptr;
   if (v.started && threadIdx.x == 0) atomicAdd(v.started, 1);
-  if constexpr (NL == 64) ols_stage_fast<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
+  if constexpr (NL == 64) ols_stage_reg<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
   else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
   else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
 }
@@ -98,17 +98,22 @@ static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_id
 }
 
 constexpr int kOlsPanelThreads = 256;   // panel width 4 (8 waves measured slower: one workgroup per CU, and a barrier-parked wave sharing the SIMD of wave 0 doubles the time of its serial solve)
-void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p) {
+// latency_bound: the final pass (k = 1: one factorisation per sample, one work-item per frame x channel).  Its 33..64-tap items
+// take the four-wave panel kernel, whose per-sample latency is lower (28 vs 34 us at 48 taps); the search (thousands of items
+// per launch) takes the one-wave kernel, whose throughput is 1.1 - 1.7 x higher.  SACAMD_OLS_FINAL_PANEL=0 / 1 overrides.
+void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int ols_class, PcmView v, double *d_p, bool latency_bound) {
   if (count <= 0) return;
   static_assert(kNumOlsClasses == 8 && kOlsClassMax[6] == 64 && kOlsClassMax[7] == 96, "instances below follow kOlsClassMax");
+  static const int force = [] { const char *e = std::getenv("SACAMD_OLS_FINAL_PANEL"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool panel = force >= 0 ? (force == 1 && latency_bound) : latency_bound;
   switch (ols_class) {
     case 0: launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p); break;
     case 1: launch_ols_c<64, 24>(s, d_items, d_idx, count, v, d_p); break;
     case 2: launch_ols_c<64, 32>(s, d_items, d_idx, count, v, d_p); break;
-    case 3: launch_ols_c<kOlsPanelThreads, 40>(s, d_items, d_idx, count, v, d_p); break;   // 40..64: multi-wave panel factorisation
-    case 4: launch_ols_c<kOlsPanelThreads, 48>(s, d_items, d_idx, count, v, d_p); break;
-    case 5: launch_ols_c<kOlsPanelThreads, 56>(s, d_items, d_idx, count, v, d_p); break;
-    case 6: launch_ols_c<kOlsPanelThreads, 64>(s, d_items, d_idx, count, v, d_p); break;
+    case 3: if (panel) launch_ols_c<kOlsPanelThreads, 40>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 40>(s, d_items, d_idx, count, v, d_p); break;
+    case 4: if (panel) launch_ols_c<kOlsPanelThreads, 48>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 48>(s, d_items, d_idx, count, v, d_p); break;
+    case 5: if (panel) launch_ols_c<kOlsPanelThreads, 56>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 56>(s, d_items, d_idx, count, v, d_p); break;
+    case 6: if (panel) launch_ols_c<kOlsPanelThreads, 64>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 64>(s, d_items, d_idx, count, v, d_p); break;
     default: launch_ols_c<256, 96>(s, d_items, d_idx, count, v, d_p); break;   // 65..96: panel factorisation, two rows per lane
   }
 }

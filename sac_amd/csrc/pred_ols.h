@@ -334,6 +334,256 @@ SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Register-resident one-wave kernel (round 3; launched for <= 64 taps).  Lane l <-> row l.  The working row V[l][*] of the
+// factorisation lives in REGISTERS and the LDL^T runs RIGHT-looking: as soon as column k is final, its term is applied to
+// every later column j,
+//     V[i][j] -= (L[i][k] * L[j][k]) * D[k]        (fused for the last term of an odd column, canon.h fold_add)
+// with L[j][k] broadcast from lane j (v_readlane: a scalar operand) -- no LDS traffic on the chain at all, where
+// ols_stage_fast pays three LDS reads per term.  Every element still sees its terms in ascending k with the reference's
+// fused / unfused pattern, so p_lpc stays bit-identical.
+// The column loop is a RUN-TIME loop over k whose body is unrolled over register slots: slot q holds column k + q, and the
+// update writes column k + 1 + q's new value into slot q (V[q] = V[q+1] - term), so the pivot column is always slot 0,
+// register indices are compile-time constants, and the code is a few KB whatever the regressor length.
+// Up to 32 taps the covariance row M[l][*] is register-resident too (MREG); beyond, it stays a packed triangle in LDS as in
+// ols_stage_fast.  The forward substitution rides along as before; the backward substitution is the unrolled end-anchored
+// chain over L in LDS (OlsBwdRows).
+template <int N> struct OlsRow { double v[N]; };
+
+// slots Q .. NMAX-2 of one column step: V[q] = V[q+1] - (lk * L[k+1+q][k]) * dk, in aligned groups of four slots under one
+// test of the group's first column against the regressor length (slots beyond it only hold values nobody reads; the four
+// independent chains of a group interleave)
+template <int NMAX, int Q>
+struct OlsRankOne {
+  // bj[u] = L[k+1+Q+u][k] of this group, requested by the previous group (or the caller): the LDS round trip of a group's
+  // broadcast reads runs under the arithmetic of the group before it
+  template <class E, class RV, class RD>
+  static SA_HD __attribute__((always_inline)) void run(E &ex, int rem /* columns after k */, const double *lrow /* &L[k+1][k] */, bool k_even, RV &V, const RD &lk, double dk,
+                                                       const double (&bj)[4]) {
+    if constexpr (Q < NMAX - 1) {
+      if (Q < rem) {
+        constexpr int QE = (Q + 4) < (NMAX - 1) ? (Q + 4) : (NMAX - 1);
+        // L[j][k], j = k + 1 + slot: read back from the column just stored to LDS -- every lane the same address (a broadcast
+        // read, two columns per ds_read2_b64) instead of two v_readlane per column.  Reads beyond the regressor length stay
+        // inside the column's zero padding.
+        double bn[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (QE < NMAX - 1) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) bn[u] = lrow[QE + u];
+        }
+        ex.par([&](int l) {
+          double tt[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (Q + u < QE) tt[u] = lk[l] * bj[u];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (Q + u < QE) {
+              // column j = k + 1 has k + 1 terms; its last one (this one) is fused when that count is odd (canon.h fold_add)
+              if (Q + u == 0) V[l].v[0] = k_even ? fma(-tt[0], dk, V[l].v[1]) : V[l].v[1] - tt[0] * dk;
+              else V[l].v[Q + u] = V[l].v[Q + u + 1] - tt[u] * dk;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (Q + u < QE) SA_PIN_F64(V[l].v[Q + u]);
+        });
+        OlsRankOne<NMAX, QE>::run(ex, rem, lrow, k_even, V, lk, dk, bn);
+      }
+    }
+  }
+};
+
+// covariance update of columns J .. NMAX-1 (ols.cpp:38-42): M[i][j] = lambda M[i][j] + ff (x_i x_j), x_j broadcast from lane j;
+// groups of four columns as in OlsRankOne
+template <int NMAX, int J>
+struct OlsCovUpdate {
+  template <class E, class RV, class RD>
+  static SA_HD __attribute__((always_inline)) void run(E &ex, int no, RV &M, const RD &xr, double lambda, double ff) {
+    if constexpr (J < NMAX) {
+      // a fresh copy of the (uniform) length now and then: otherwise the compiler evaluates all "j < no" tests of the unrolled
+      // code once, ahead of the sample loop, and keeps their lane masks alive (spilled to VGPR lanes)
+      if constexpr ((J & 7) == 0) SA_OPAQUE_SINT(no);
+      if (J < no) {
+        constexpr int JE = (J + 4) < NMAX ? (J + 4) : NMAX;
+        double xj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (J + u < JE) xj[u] = ex.lane_bcast(xr, J + u);
+        ex.par([&](int l) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (J + u < JE) M[l].v[J + u] = fma(lambda, M[l].v[J + u], ff * (xr[l] * xj[u]));
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (J + u < JE) SA_PIN_F64(M[l].v[J + u]);
+        });
+        OlsCovUpdate<NMAX, JE>::run(ex, no, M, xr, lambda, ff);
+      }
+    }
+  }
+};
+
+template <class E, int NMAX>
+SA_HD void ols_stage_reg(E &ex, const ChanParam &p, const int *self, const int *other, int n,
+                         double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
+  static_assert(E::nl == 64 && NMAX <= 64 && NMAX % 4 == 0, "one-wave path");
+  constexpr bool MREG = NMAX <= 32;         // covariance rows in registers (else: packed triangle in LDS)
+  constexpr int S = NMAX + kOlsPad;
+  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
+#define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
+  constexpr int NL = 64;
+  const int no = E::uniform(p.n_ols);
+  const int ntri = tri_count(no);
+  OlsLdsFast L;
+  L.carve(lds_base, NMAX);
+  const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
+
+  typename E::template Reg<double> xr, breg, sreg, zreg, invd_mine, lk, dacc;
+  typename E::template Reg<OlsRow<MREG ? NMAX : 1>> M;
+  typename E::template Reg<OlsRow<NMAX>> V;
+  typename E::template Reg<int> xnext;
+
+  ex.par([&](int l) {
+    xr[l] = 0.0; breg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; invd_mine[l] = 0.0; lk[l] = 0.0; dacc[l] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NMAX; j++) { if (MREG) M[l].v[j] = 0.0; V[l].v[j] = 0.0; }
+    if (l < no) L.X[l] = 0.0;
+    for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
+    if (!MREG) for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
+    for (int e = l; e < NMAX * S; e += NL) L.Lq[e] = 0.0;
+    sa_stage_tables(L.libm, l, NL);
+    xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
+  });
+  ex.sync();
+
+  double esum = 0.0;
+  int km = 0;
+  const double lambda = p.lambda, nu = p.nu_eff;
+  const double one_m_lambda = 1.0 - lambda;
+
+  if (prof) tc = E::clock();
+  int sv_ahead = n > 0 ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
+  for (int t = 0; t < n; t++) {
+    const int sv = sv_ahead;
+    if (t + 1 < n) sv_ahead = self[t + 1];
+    ex.par([&](int l) {
+      xr[l] = (double)xnext[l];
+      if (l < no) L.X[l] = xr[l];
+      if (l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
+    });
+    ex.sync();
+    double pred = 0.0, val = 0.0, ff = 0.0;
+    ex.par([&](int l) {          // slmath::dot with its eight FMA accumulators spread over lanes
+      const int a = l & 7;
+      double c = 0.0;
+      for (int i = 0; i + 8 <= no; i += 8) c = fma(L.X[i + a], L.Wv[i + a], c);
+      dacc[l] = c;
+    });
+    ex.uni([&]() {
+      pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
+      val = (double)sv;
+      const double e = val - pred;
+      esum = fma(p.beta_sum, esum, fabs(e));
+      const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
+      ff = one_m_lambda * c;
+    });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
+    SA_TICK(0);
+    if constexpr (MREG) {
+      OlsCovUpdate<NMAX, 0>::run(ex, no, M, xr, lambda, ff);
+      ex.par([&](int l) { breg[l] = fma(lambda, breg[l], ff * (xr[l] * val)); });
+    } else {
+      // covariance / rhs update on the packed triangle in LDS (ols.cpp:38-45): lane = row i, loop over columns j <= i.
+      // Loads are unconditional (rows above the diagonal read harmless neighbours), only the stores are masked.
+      ex.par([&](int l) {
+        if (l < no) {
+          const double xi = xr[l];
+          int j = 0;
+          double *dump = L.dump;                       // write-only slot
+          for (; j + 8 <= no; j += 8) {
+            double m[8], xj[8];
+            int e[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { e[u] = tri_off(no, j + u) + (l - (j + u)); xj[u] = L.X[j + u]; m[u] = L.M[e[u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const double v = fma(lambda, m[u], ff * (xi * xj[u]));
+              double *dst = (l >= j + u) ? &L.M[e[u]] : dump;      // select the address, not the lane
+              *dst = v;
+            }
+          }
+          for (; j < no; j++) { const int e = tri_off(no, j) + (l - j); const double v = fma(lambda, L.M[e], ff * (xi * L.X[j])); if (l >= j) L.M[e] = v; }
+          breg[l] = fma(lambda, breg[l], ff * (xi * val));
+        }
+      });
+    }
+    SA_TICK(1);
+    km++;
+    if (km >= p.k) {
+      km = 0;
+      // working copy: slot j = column j of A + nu I (lower triangle; the rest is never read)
+      if constexpr (MREG) {
+        ex.par([&](int l) {
+#pragma unroll
+          for (int j = 0; j < NMAX; j++) V[l].v[j] = (l == j) ? M[l].v[j] + nu : M[l].v[j];
+        });
+      } else {
+        ex.wsync();
+        ex.par([&](int l) {
+          const int lm = l < no ? l : no - 1;
+          int oj = 0;                                 // tri_off(no, j)
+#pragma unroll
+          for (int j = 0; j < NMAX; j++) {
+            if (j < no) {
+              const double m = L.M[oj + (lm - j)];
+              V[l].v[j] = (l == j) ? m + nu : m;
+              oj += no - j;
+            }
+          }
+        });
+      }
+      ex.par([&](int l) { sreg[l] = breg[l]; });     // forward substitution starts from b
+      bool ok = true;
+      for (int k = 0; k < no; k++) {
+        const double dk = ex.lane_bcast_col(V, 0, k);              // pivot D[k] = V[k][k] (slot 0 = column k)
+        if (dk < 1e-12) { ok = false; break; }
+        const double invd = 1.0 / dk;
+        const double yk = ex.lane_bcast(sreg, k);                  // forward substitution: y[k] is final (math.h:58-66)
+        ex.par([&](int l) {
+          const double lp = V[l].v[0] * invd;                      // L[i][k] = lij * invD (math.h:49)
+          lk[l] = lp;
+          if (l > k && l < no) L.Lq[k * S + l] = lp;
+          if (l == k) invd_mine[l] = invd;
+          const double v = fold_fused(k, l) ? fma(-lp, yk, sreg[l]) : sreg[l] - lp * yk;
+          if (l > k && l < no) sreg[l] = v;
+        });
+        ex.wsync();                                   // the column is in LDS (one wave: LDS traffic is in order, only the compiler needs the fence)
+        int rem = no - 1 - k;
+        SA_OPAQUE_SINT(rem);
+        const double *lrow = L.Lq + k * S + k + 1;
+        const double b0[4] = {lrow[0], lrow[1], lrow[2], lrow[3]};
+        OlsRankOne<NMAX, 0>::run(ex, rem, lrow, (k & 1) == 0, V, lk, dk, b0);
+      }
+      SA_TICK(2);
+      if (ok) {
+        ex.par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
+        SA_TICK(3);
+        ex.par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS for the chain below
+        ex.wsync();
+        ex.lane0([&]() {
+          double wr[NMAX];
+          const double *lb = L.Lq - (NMAX - no) * (S + 1);          // lb[(NMAX-1-ip)*S + (NMAX-1-kp)] == L[k][i]
+          const double *zb = L.Dv - (NMAX - no);                    // zb[NMAX-1-ip] == z[i]
+          double *wb = L.Wv - (NMAX - no);
+          OlsBwdRows<NMAX, S, 0>::run(no, L.X, lb, zb, wb, wr);
+        });
+        ex.wsync();
+        SA_TICK(4);
+      }
+    }
+    ex.sync();
+    SA_TICK(5);
+  }
+  if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[i] = tp[i]; });
+#undef SA_TICK
+}
+
+// ---------------------------------------------------------------------------------------------
 // Multi-wave variant of ols_stage_fast for the long regressors (E::nl == 64*PW with PW = 4 or 8,
 // n_ols <= 64): same arithmetic, element for element, but the LDL^T runs as a blocked left-looking
 // factorisation with panels of PW columns:

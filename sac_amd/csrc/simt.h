@@ -25,8 +25,12 @@
 // hide an integer's value from the optimiser (device: it lives in one VGPR; host: no-op)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SA_OPAQUE_INT(x) asm volatile("" : "+v"(x))
+#define SA_OPAQUE_SINT(x) asm volatile("" : "+s"(x))      // same for a wave-uniform value held in an SGPR
+#define SA_PIN_F64(x) asm volatile("" : "+v"(x))          // the computation of x stays in this basic block (not sunk / merged across branches)
 #else
+#define SA_PIN_F64(x) ((void)0)
 #define SA_OPAQUE_INT(x) ((void)0)
+#define SA_OPAQUE_SINT(x) ((void)0)
 #endif
 
 namespace sacamd {
@@ -71,6 +75,8 @@ struct ExecEmu {
   void sync() {}
   template <class T> T lane_get(const Reg<T> &r, int k) { return r[k]; }
   double lane_bcast(const Reg<double> &r, int k) { return r[k]; }
+  template <class R> double lane_bcast_col(const R &r, int col, int k) { return r[k].v[col]; }   // element `col` of lane k's register array
+  template <int K> double lane_bcast_at(const Reg<double> &r) { return r[K]; }                   // lane_bcast, K a compile-time lane, not moved by the compiler
   // inside par(): the value lane k (0..63) of lane l's own wave holds
   double wave_lane(const Reg<double> &r, int l, int k) { return r[(l & ~63) | k]; }
   int lane_geti(const Reg<int> &r, int k) { return r[k]; }
@@ -79,6 +85,9 @@ struct ExecEmu {
   // trip count of a loop whose length differs between the waves of a workgroup: lanes < split run a iterations, the others
   // b (device: the calling wave's own count, wave-uniform; the emulator runs the lanes of all waves in one loop)
   int wave_hops(int, int a, int b) { return a > b ? a : b; }
+  // a value every lane of the wave holds alike, made known as such to the compiler (device: v_readfirstlane -> SGPR, so that
+  // branches on it are scalar branches)
+  static int uniform(int v) { return v; }
   // code only lane 0 executes: run once
   template <class F> void lane0(F &&f) { f(); }
   static unsigned long long clock() { return 0; }
@@ -202,6 +211,7 @@ struct ExecDev {
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
     r.v = __hiloint2double(hi, lo);
   }
+  static SA_D int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
   SA_D int wave_hops(int split, int a, int b) { return __builtin_amdgcn_readfirstlane((int)threadIdx.x < split ? a : b); }
   template <class F> SA_D void lane0(F &&f) { if (threadIdx.x == 0) f(); }
   static SA_D unsigned long long clock() { return __builtin_readcyclecounter(); }
@@ -216,6 +226,19 @@ struct ExecDev {
   SA_D double lane_bcast(const Reg<double> &r, int k) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(r.v), k & 63);   // k may be a workgroup-wide lane index
     const int hi = __builtin_amdgcn_readlane(__double2hiint(r.v), k & 63);
+    return __hiloint2double(hi, lo);
+  }
+  template <class R> SA_D double lane_bcast_col(const R &r, int col, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(r.v.v[col]), k & 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(r.v.v[col]), k & 63);
+    return __hiloint2double(hi, lo);
+  }
+  // v_readlane as volatile inline assembly: stays where it is written (the compiler otherwise hoists the broadcasts of an
+  // unrolled column loop to its top and spills the scalar registers they occupy)
+  template <int K> SA_D double lane_bcast_at(const Reg<double> &r) {
+    int lo, hi;
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(lo) : "v"(__double2loint(r.v)), "n"(K));
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(hi) : "v"(__double2hiint(r.v)), "n"(K));
     return __hiloint2double(hi, lo);
   }
   SA_D double wave_lane(const Reg<double> &r, int, int k) { return lane_bcast(r, k); }

@@ -43,7 +43,7 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     if (p.n_ols > kMaxOLS) return -1;
     {
 #define EMU_OLSP(NM) { std::vector<char> lds(ols_panel_lds_bytes(NM, 4)); ExecEmu<256> ex; ols_stage_panel<ExecEmu<256>, NM>(ex, p, self, other, n, pl, lds.data()); }
-#define EMU_OLS(NM) { std::vector<char> lds(OlsLdsFast::bytes(NM)); ExecEmu<64> ex; ols_stage_fast<ExecEmu<64>, NM>(ex, p, self, other, n, pl, lds.data()); }
+#define EMU_OLS(NM) { std::vector<char> lds(OlsLdsFast::bytes(NM)); ExecEmu<64> ex; ols_stage_reg<ExecEmu<64>, NM>(ex, p, self, other, n, pl, lds.data()); }
       if (!optimize) {     // as the host (build_items): the final pass uses the 32 / 64 / 96-tap capacity classes only
         if (p.n_ols <= 32) EMU_OLS(32)
         else if (p.n_ols <= 56) EMU_OLSP(56)
@@ -53,10 +53,10 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
       else if (p.n_ols <= 16) EMU_OLS(16)
       else if (p.n_ols <= 24) EMU_OLS(24)
       else if (p.n_ols <= 32) EMU_OLS(32)
-      else if (p.n_ols <= 40) EMU_OLSP(40)     // as the launcher: four-wave panel path from 33 on
-      else if (p.n_ols <= 48) EMU_OLSP(48)
-      else if (p.n_ols <= 56) EMU_OLSP(56)
-      else if (p.n_ols <= 64) EMU_OLSP(64)
+      else if (p.n_ols <= 40) EMU_OLS(40)     // as the launcher: one wave up to 64 taps
+      else if (p.n_ols <= 48) EMU_OLS(48)
+      else if (p.n_ols <= 56) EMU_OLS(56)
+      else if (p.n_ols <= 64) EMU_OLS(64)
       else { std::vector<char> lds(ols_panel2_lds_bytes(96)); ExecEmu<256> ex; ols_stage_panel2<ExecEmu<256>, 96>(ex, p, self, other, n, pl, lds.data()); }   // 65..96 taps: two rows per lane
     }
     std::vector<double> tab; double sp[4];

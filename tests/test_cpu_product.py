@@ -310,3 +310,25 @@ def test_canonical_cascade_layout_boundaries_emulated_vs_oracle(emu, orc, taps):
     assert np.array_equal(plpc.view(np.uint64), ol.view(np.uint64))
     assert np.array_equal(psum.view(np.uint64), (ol + om).view(np.uint64))
     assert np.array_equal(err, oe)
+
+
+@pytest.mark.parametrize("nA,nM0,opt", [(5, 0, 0), (16, 1, 1), (17, 0, 0), (24, 0, 1), (25, 7, 0), (32, 1, 1), (32, 8, 0), (32, 15, 1), (32, 16, 0),
+                                        (32, 17, 1), (32, 24, 0), (32, 31, 1), (32, 32, 0), (32, 32, 1)])
+def test_register_resident_ols_kernel_body_vs_oracle(emu, orc, nA, nM0, opt):
+    """The one-wave OLS kernel body (right-looking LDL^T on register rows, run-time column loop with rotating register
+    slots; covariance in registers up to 32 taps, in LDS up to 64) at regressor lengths around every capacity class
+    boundary, k = 1 and k = 4: p_lpc bit-identical to the oracle (itself pinned to the genuine reference)."""
+    from sac_amd.synth import synth_pcm
+    n = 220
+    raw = synth_pcm(n, 1, 300 + nA + nM0, 8000)
+    g = np.ascontiguousarray(orc.profile()[:, 2].copy(), np.float32)
+    g[24], g[9] = nA, nM0
+    g[28], g[29], g[30], g[37] = 64, 32, 16, 4          # short cascade: this test is about stage 1
+    smp, stats = center_frame(raw)
+    plpc = np.zeros((1, n)); psum = np.zeros((1, n)); err = np.zeros((1, n), np.int32); pred = np.zeros((1, n), np.int32)
+    rc = emu.emu_predict(1, n, _vp(np.ascontiguousarray(smp, np.int32)), _vp(np.ascontiguousarray(stats, np.int32)), _vp(g), 0, n, opt, 4,
+                         _vp(plpc), _vp(psum), _vp(err), _vp(pred))
+    assert rc == 0
+    pd, ol, om, oe = orc.predict_trace(smp, stats, g, 0, n, opt)
+    assert np.array_equal(plpc.view(np.uint64), ol.view(np.uint64))
+    assert np.array_equal(err, oe) or opt          # search evaluations: free-order cascade sums (tolerance elsewhere)
