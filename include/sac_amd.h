@@ -14,11 +14,8 @@
  * take turns with their search phases (one search saturates the chip).  There is no CPU fallback: if no
  * gfx950 device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
  *
- * Environment switches, all default off and all measured as losses on MI355X: SACAMD_TAIL_HI=1 runs the
- * tail of a batch (final pass + coder) on two extra stream sets (SACAMD_POOL_PRIO=1: created with high priority),
- * SACAMD_TAIL_PRIO=1 raises the wave priority of the tail kernels, SACAMD_CHASE=1 runs the final pass's cascade
- * kernels concurrently with its OLS kernels, SACAMD_BIG_FIRST=1 launches the whole-CU cascade layout of the final pass
- * before the others.  SACAMD_TRACE=1 prints every predictor launch with its duration.
+ * Environment switches: SACAMD_TRACE=1 prints every predictor launch with its duration; SACAMD_CANON_SYSTOLIC=1 selects the
+ * round-2 cascade layouts for the final pass and SACAMD_OLS_FINAL_PANEL=0 the one-wave OLS kernel for it (A/B measurements).
  */
 #ifndef SAC_AMD_H
 #define SAC_AMD_H
@@ -149,6 +146,16 @@ int sacamd_plan_subframes(sacamd_ctx *ctx, const int32_t *pcm_planar, long long 
 int sacamd_subframes_from_states(const int *block_state, const int *block_len, int nblocks, int min_frame_length,
                                  sacamd_subframe *out, int cap, int *count);
 
+/* ---- (8) decode ------------------------------------------------------------------------------------
+ * Replaces: per frame FrameCoder::ReadEncoded (libsac.cpp:580-594) + Decode (:496-505: RangeCoderSH + [MapEncoder +]
+ * BitplaneCoder::Decode per channel) + UnpredictFrame (:144-199), i.e. the body of Codec::DecodeFile's frame loop
+ * (:857-883), for nframes frame records at once.  recs holds the records back to back, rec_off[f]..rec_off[f+1]
+ * delimit frame f (as sacamd_encode_frames writes them / as they lie in a .sac file behind its header).  Output: planar
+ * int32 PCM, pcm_out[f*frame_stride + ch*ch_stride + i], numsamples_out[f] (nullable), profiles_out [nframes][58]
+ * (nullable).  The context must have been created for the channel count and frame sizes of the records. */
+int sacamd_decode_frames(sacamd_ctx *ctx, int nframes, int framesize, const uint8_t *recs, const long long *rec_off,
+                         int32_t *pcm_out, long long frame_stride, long long ch_stride, int *numsamples_out, float *profiles_out);
+
 /* ---- multi-GPU sharding (host only) ----------------------------------------------------------
  * Frames are independent units (with cfg.reset): owner[f] = rank that encodes frame f, assigned longest-first by the
  * caller's cost estimate (channels * (evaluations * search window + frame length)) to the least loaded of `world`
@@ -169,13 +176,14 @@ int sacamd_debug_cost(sacamd_ctx *ctx, int kind, const int32_t *err, int n, doub
  * [0] analyse [1] tables [2] ols [3] lms [4] bias [5] cost [6] s2u/remap [7] coder; launches in [8..15] */
 int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
 
-/* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*8 + class)*4 + {0,1,2,3}] =
+/* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*16 + slot)*4 + {0,1,2,3}] =
  * total ms (HIP events on the launch's stream), launches, item-steps processed, algorithmic fp64 flops (FMA = 2,
- * SURVEY.md 8d formula with each item's actual regressor length / tap counts); kind 0 = OLS capacity
- * classes 0..7 (16,24,32 taps: k_ols<64,NMAX>; 40..96: k_ols<256,NMAX>), kind 1 = cascade layout classes 0..15
- * (0..6: search layouts, 7..9 and 10..13: canonical-order layouts of the final pass).  out receives (8 + 16) * 4 = 96
- * entries; cap = capacity of out in doubles (SACAMD_ERR_ARG if smaller).  ABI version 2 (version 1 had no cap and 80 entries). */
-int sacamd_class_times(sacamd_ctx *ctx, double *out96, int cap, int reset);
+ * SURVEY.md 8d formula with each item's actual regressor length / tap counts).  kind 0 = OLS: slots 0..7 = capacity
+ * classes 16,24,32,40,48,56,64 taps (k_ols<64,NMAX>, one wave) and 96 (k_ols<256,96>); slots 11..14 = the four-wave panel
+ * kernels k_ols<256,40..64> the final pass uses for its 33..64-tap items.  kind 1 = cascade layout classes 0..15 (0..6:
+ * search layouts, 7..9 and 10..13: canonical-order layouts of the final pass).  out receives 2 * 16 * 4 = 128 entries;
+ * cap = capacity of out in doubles (SACAMD_ERR_ARG if smaller).  ABI version 2 (version 1 had no cap and 80 entries). */
+int sacamd_class_times(sacamd_ctx *ctx, double *out128, int cap, int reset);
 
 /* Progress of a running sacamd_encode_frames on this context; may be called from another thread while that call
  * is in flight (the only entry point that may).  phase: 0 idle, 1 DDS search, 2 final prediction pass, 3 entropy

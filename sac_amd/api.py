@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
     "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
+    "sacamd_decode_frames",
 ]
 
 
@@ -229,6 +230,20 @@ class Context:
         recs = [out[off[f]: off[f + 1]].tobytes() for f in range(self.nframes)]
         return recs, prof
 
+    def decode_frames(self, recs, framesize):
+        """Frame records (bytes, as encode_frames returns them / as they lie in a .sac file) -> (list of PCM arrays
+        [nch, numsamples] int32, profiles [nframes, 58]): ReadEncoded + Decode + Unpredict of every frame on the GPU."""
+        nf = len(recs)
+        blob = np.frombuffer(b"".join(recs), np.uint8).copy()
+        off = np.zeros(nf + 1, np.int64)
+        off[1:] = np.cumsum([len(r) for r in recs])
+        out = np.zeros((nf, self.nch, self.max_framesize), np.int32)
+        ns = np.zeros(nf, np.int32)
+        prof = np.zeros((nf, NUM_COEFS), np.float32)
+        self._chk(self.lib.sacamd_decode_frames(self.h, nf, int(framesize), _vp(blob), _vp(off), _vp(out), c_longlong(self.nch * self.max_framesize),
+                                                c_longlong(self.max_framesize), _vp(ns), _vp(prof)))
+        return [out[f, :, : ns[f]].copy() for f in range(nf)], prof
+
     # ---- adaptive sub-frame split + batch file driver (Codec::Analyse / Codec::EncodeFile's frame loop)
     def plan_subframes(self, pcm, blocksamples, min_frame_length, samples_read=None):
         """pcm [nch, n] int32 (raw, un-centred) -> [(start, length, state)] as Codec::Analyse cuts one read."""
@@ -315,11 +330,11 @@ class Context:
 
     def class_times(self, reset=True):
         """per kernel instance: {(kind, class): (ms, launches, item_steps, fp64 flops)}, kind 'ols' | 'lms'."""
-        out = np.zeros(96)
+        out = np.zeros(128)
         self._chk(self.lib.sacamd_class_times(self.h, _vp(out), out.size, int(reset)))
-        o = out.reshape(24, 4)
-        res = {("ols", c): tuple(o[c]) for c in range(8) if o[c, 1] > 0}
-        res.update({("lms", c): tuple(o[8 + c]) for c in range(16) if o[8 + c, 1] > 0})
+        o = out.reshape(32, 4)
+        res = {("ols", c): tuple(o[c]) for c in range(16) if o[c, 1] > 0}
+        res.update({("lms", c): tuple(o[16 + c]) for c in range(16) if o[16 + c, 1] > 0})
         return res
 
     def progress(self):

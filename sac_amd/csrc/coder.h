@@ -15,6 +15,7 @@
 // 4.5 MB Laplace table (precomputed on the host with the reference's libm expressions,
 // vle.cpp:70-79) live in HBM/L2.
 #pragma once
+#include <type_traits>
 #include "simt.h"
 
 namespace sacamd {
@@ -93,6 +94,24 @@ struct RangeEnc {            // RangeCoderSH, encode side
     while (range < 0x01000000u) { range <<= 8; shift_low(); }
   }
   SA_HD void stop() { for (int i = 0; i < 5; i++) shift_low(); }
+};
+
+struct RangeDec {            // RangeCoderSH, decode side (model/range.cpp:54-83)
+  unsigned range, code;
+  const unsigned char *in;   // staged input window (LDS) or the stream itself
+  int pos, len;              // bytes consumed / available
+  SA_HD unsigned get() { const unsigned b = pos < len ? in[pos] : 0u; pos++; return b; }   // BufIO::GetByte past the end reads the buffer's zero fill
+  SA_HD void init(const unsigned char *src, int n) {
+    range = 0xFFFFFFFFu; code = 0; in = src; pos = 0; len = n;
+    for (int i = 0; i < 5; i++) code = (code << 8) + get();      // NUM + 1 bytes; the first is the encoder's initial Cache (0)
+  }
+  SA_HD int decode(unsigned p1) {
+    const unsigned rnew = (unsigned)(((unsigned long long)range * ((unsigned)(kPScale - p1) << (32 - kPBits))) >> 32);
+    const int bit = code >= rnew;
+    if (bit) { range -= rnew; code -= rnew; } else range = rnew;
+    while (range < 0x01000000u) { range <<= 8; code = (code << 8) + get(); }
+    return bit;
+  }
 };
 
 // round-half-away-from-zero shifts (val < 0 ? -((-val + h) >> s) : (val + h) >> s), written without a
@@ -252,10 +271,13 @@ SA_HD CoderDescR coder_describe(const CoderWin &W, const CoderTabs &T, int i, in
 
 // ---- the adaptive chain for one decision.  c1sig: the (possibly prefetched) csig0 entry for a
 // significance decision; returns its updated value through *c1out.
-SA_HD void coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, CntL c1sig, CntL *c1out, RangeEnc &rc) {
+// RC = RangeEnc: the bit is D's; RC = RangeDec: the bit comes from the stream (BitplaneCoder::Decode, vle.cpp:233-261).  Returns it.
+template <class RC>
+SA_HD int coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, CntL c1sig, CntL *c1out, RC &rc) {
   const int pest = D.a & 0xffff, i1 = (D.a >> 16) & 0xffff, i2 = D.b & 0xffff, i3 = (D.b >> 16) & 0xffff;
   const int i4 = D.c & 0xffff, mixc = (D.c >> 16) & 0xff, s1 = (D.c >> 24) & 0xff, s2 = D.d & 0xff;
-  const int type = (D.d >> 8) & 1, bit = (D.d >> 9) & 1, st_pest = (short)(D.d >> 16);
+  const int type = (D.d >> 8) & 1, st_pest = (short)(D.d >> 16);
+  int bit = (D.d >> 9) & 1;
   (void)pest;
   // ---- round 1: every state word this decision touches
   const CntL pl = M.p_laplace[bpn];
@@ -291,7 +313,7 @@ SA_HD void coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, 
   const int pr2 = sse_interp<15>(m2a, m2b, r2);
   int sf[2] = {fwd_at(T, (pr1 + pr2 + 1) >> 1), sp1};
   const int p = (int)(pinv_lookup(T.pinv, mix_dot<2>(sw, sf)) & 0xffff);
-  rc.encode((unsigned)p, bit);
+  if constexpr (std::is_same<RC, RangeDec>::value) bit = rc.decode((unsigned)p); else rc.encode((unsigned)p, bit);
   // ---- updates (computed from the loaded values; stores only)
   M.p_laplace[bpn] = cntl_next(pl, bit, 150, T.divt);
   if (type) {
@@ -313,6 +335,7 @@ SA_HD void coder_step(CoderModel &M, const CoderTabs &T, CoderDescR D, int bpn, 
   m2[q2] = cnt16_next(m2a, bit, 250); m2[q2 + 1] = cnt16_next(m2b, bit, 250); M.sse_lb[s2] = (unsigned char)bit;
   mix_next<2>(sw, sf, p, bit, 250);
   M.ssemix[0] = sw[0]; M.ssemix[1] = sw[1];
+  return bit;
 }
 
 #if defined(__HIPCC__)
@@ -429,11 +452,14 @@ SA_HD void map_model_init(MapModel &m, const unsigned *pinv) {
   m.finalmix[0] = m.finalmix[1] = 0; m.lb = 0;
   for (int i = 0; i <= 32; i++) { const int x = squash(pinv, i * 171 - 2662); m.sse[0][i] = (unsigned short)x; m.sse[1][i] = (unsigned short)x; }   // SSENL<32>: xscale 171
 }
-SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char *uh, const CoderTabs &T, RangeEnc &rc) {
+// RC = RangeEnc: MapEncoder::Encode over the flags ul / uh; RC = RangeDec: MapEncoder::Decode (map.cpp:87-101) INTO them
+// (ul[0] / uh[0] are never coded and must be 0 on entry)
+template <class RC, class U>
+SA_HD void map_code(MapModel &m, U *ul, U *uh, const CoderTabs &T, RC &rc) {
   const unsigned *pinv = T.pinv;
   for (int i = 1; i <= 1 << 15; i++) {
     for (int hi = 0; hi < 2; hi++) {
-      const unsigned char *a = hi ? uh : ul;
+      U *a = hi ? uh : ul;
       const int ctx1 = a[i - 1];
       const int ctx2 = hi ? ul[i] : uh[i - 1];
       const int ctx3 = i > 1 ? a[i - 2] : 0;
@@ -454,8 +480,9 @@ SA_HD void map_encode(MapModel &m, const unsigned char *ul, const unsigned char 
       const int ps = sse_interp<32>(mp[q], mp[q + 1], r);
       int sf[2] = {fwd_at(T, ps), sp1};
       const int p = (int)(pinv_lookup(pinv, mix_dot<2>(m.finalmix, sf)) & 0xffff);
-      const int bit = a[i];
-      rc.encode((unsigned)p, bit);
+      int bit;
+      if constexpr (std::is_same<RC, RangeDec>::value) { bit = rc.decode((unsigned)p); a[i] = (unsigned char)bit; }
+      else { bit = a[i]; rc.encode((unsigned)p, bit); }
       cnt16_update(*pc1, bit, 500); cnt16_update(*pc2, bit, 500); cnt16_update(*pc3, bit, 500); cnt16_update(*pc4, bit, 500); cnt16_update(*px, bit, 500);
       mix_next<5>(w, st, p1, bit, 1000);
       cnt16_update(mp[q], bit, 300); cnt16_update(mp[q + 1], bit, 300); m.lb = bit;
@@ -492,7 +519,7 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
   };
   if (used) {
     ex.par([&](int l) {
-      if (l == 0) { map_model_init(MM, T.pinv); map_encode(MM, used, used + 32769, T, rc); publish(); }
+      if (l == 0) { map_model_init(MM, T.pinv); map_code(MM, used, used + 32769, T, rc); publish(); }
     });
     ex.sync();
   }
@@ -584,6 +611,77 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
   int len = 0;
   ex.lane0([&]() { rc.stop(); rc.flush_serial(); len = rc.pos; });
   return len;   // valid on lane 0
+}
+
+// ---- whole stream, decode side: BitplaneCoder::Decode (vle.cpp:233-261) + RangeCoderSH::DecodeBitOne [+ MapEncoder::Decode].
+// E::nl == 64.  The contexts of a sample in plane b depend on the bits of ITS LEFT NEIGHBOURS in the same plane, so -- unlike
+// the encoder -- nothing can be described ahead: every decision describes its sample from the window of PARTIAL values
+// (bits above the plane for the sample and its right neighbours, bits down to the plane for its left neighbours; masking
+// a partial value with the encoder's masks leaves it unchanged, so coder_describe is used as it is) and then runs the
+// adaptive chain; lane 0 does both.  The window of a 64-sample chunk (+ 32 either side) is staged in LDS, updated in place
+// and written back to `s2u` (global, zero-initialised here) at the end of the chunk; the input bytes of a chunk are staged
+// in LDS too (a chunk consumes at most 2 bytes per decision).  Returns the number of input bytes consumed (lane 0).
+constexpr int kDecStage = 256;
+template <class E>
+SA_HD int coder_stream_dec(E &ex, const unsigned char *in, int inlen, int n, int maxbpn, unsigned char *used_out /*nullable: usedl, usedh [2][32769]*/,
+                           const unsigned short *laplace, const unsigned short *plap_init, CntL *csig0, int *s2u /*out [n]*/,
+                           CoderModel &M, const CoderTabs &T, CoderWin &W, MapModel &MM) {
+  static_assert(kDecStage <= kCoderStage, "input staging shares the encoder's output staging buffer");
+  ex.par([&](int l) {
+    for (int i = l; i < 65536; i += E::nl) { csig0[i].p1 = kPScale >> 1; csig0[i].cnt = 0; }
+    for (int i = l; i < n; i += E::nl) s2u[i] = 0;
+    if (used_out) for (int i = l; i < 2 * 32769; i += E::nl) used_out[i] = 0;
+  });
+  ex.gsync();
+  ex.par([&](int l) { coder_model_init(M, T, plap_init, l, E::nl); if (l == 0) { W.fl[0] = 0; W.fl[1] = 0; } });
+  ex.sync();
+  RangeDec rc;
+  rc.init(in, inlen);                       // the five priming bytes and the map header come straight from the stream
+  if (used_out) {
+    ex.lane0([&]() { map_model_init(MM, T.pinv); map_code(MM, used_out, used_out + 32769, T, rc); });
+    ex.gsync();
+  }
+  int consumed = rc.pos;                    // stream position of W.stage[0] (uniform: broadcast from lane 0 through LDS)
+  ex.lane0([&]() { W.fl[0] = rc.pos; });
+  ex.sync();
+  consumed = W.fl[0];
+  for (int bpn = maxbpn; bpn >= 0; bpn--) {
+    for (int s0 = 0; s0 < n; s0 += kCoderChunk) {
+      ex.par([&](int l) {
+        for (int q = l; q < kCoderChunk + 2 * kCoderHalo; q += E::nl) {
+          const int k = s0 - kCoderHalo + q;
+          const int v = (k >= 0 && k < n) ? s2u[k] : 0;
+          W.val[q] = v;
+          W.msb[q] = (unsigned char)(v > 0 ? ilog2i(v) : 0);
+        }
+        for (int q = l; q < kDecStage; q += E::nl) W.stage[q] = consumed + q < inlen ? in[consumed + q] : (unsigned char)0;
+      });
+      ex.sync();
+      const int cnt = (n - s0 < kCoderChunk) ? n - s0 : kCoderChunk;
+      ex.lane0([&]() {
+        rc.in = W.stage; rc.pos = 0; rc.len = kDecStage;
+        for (int i = 0; i < cnt; i++) {
+          const int li = i + kCoderHalo;
+          const CoderDescR D = coder_describe(W, T, i, s0 + i, n, bpn, laplace);
+          const bool is_sig = !((D.d >> 8) & 1);
+          const int idx = (D.a >> 16) & 0xffff;
+          CntL cur = csig0[is_sig ? idx : 0], upd = cur;
+          const int bit = coder_step(M, T, D, bpn, cur, &upd, rc);
+          if (is_sig) csig0[idx] = upd;
+          if (bit) {
+            W.val[li] += 1 << bpn;
+            if (is_sig) W.msb[li] = (unsigned char)bpn;
+          }
+        }
+        W.fl[0] = consumed + rc.pos;
+      });
+      ex.sync();
+      consumed = W.fl[0];
+      ex.par([&](int l) { if (l < cnt) s2u[s0 + l] = W.val[l + kCoderHalo]; });
+      ex.gsync();
+    }
+  }
+  return consumed;
 }
 
 }  // namespace sacamd

@@ -94,12 +94,8 @@ struct sacamd_ctx {
   hipStream_t stream = nullptr;
   static constexpr int kSide = 13;                 // logical side streams: 8 OLS classes + 4 cascade launches + 1 marker
   hipStream_t cls_stream[kSide] = {};
-  // `stream` / `cls_stream` are the ACTIVE set, taken from the per-device pool (DevStreams below): lane 0 = the
-  // normal set shared by all contexts of the device, lane 1 = one of two high-priority sets that
-  // sacamd_encode_frames switches to for the latency-bound tail of a batch (final pass + coder)
-  int lane = 0;
-  hipStream_t own_main = nullptr;                  // this context's main stream of the normal set (the side streams are pooled)
-  int tail_hi = 0, tail_prio = 0;                  // SACAMD_TAIL_HI / SACAMD_TAIL_PRIO (default off): tail on the high-priority streams / with raised wave priority
+  // `cls_stream` come from the per-device pool (DevStreams below), shared by all contexts of the device
+  hipStream_t own_main = nullptr;                  // this context's main stream (the side streams are pooled)
   hipEvent_t ev_fork = nullptr, ev_join[kSide] = {}, ev_ols[kNumOlsClasses] = {};
   std::string err;
   unsigned long long *d_prof = nullptr;   // debug: OLS section counters
@@ -119,9 +115,6 @@ struct sacamd_ctx {
   DevBuf<unsigned char> d_used;
   // predictor scratch
   DevBuf<WorkItem> d_items;
-  DevBuf<int> d_progress;     // final pass: per work-item OLS progress + [count] = number of OLS workgroups begun (PcmView::progress / started)
-  int big_first = 0;          // SACAMD_BIG_FIRST (default off: measured no gain, 243.8 vs 242.2 s): final pass launches whole-CU cascade layouts before the two-per-CU ones
-  int chase = 0;              // SACAMD_CHASE (default off, measured slower): run the final pass's cascade kernels concurrently with its OLS kernels
   DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist, d_nf;   // d_nf: per work-item "prediction not finite" flags of the last run_predict
   std::vector<int> h_nf;
   DevBuf<double> d_tab, d_p, d_q, d_cost;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
@@ -138,6 +131,10 @@ struct sacamd_ctx {
   DevBuf<CoderJob> d_jobs;
   DevBuf<RemapJob> d_rj;
   DevBuf<int> d_prefix, d_tmp_s2u, d_tmp_mb;
+  DevBuf<DecLink> d_declink;      // decoder: per (stage, work-item) hand-off descriptors
+  DevBuf<int> d_decprog;          // decoder: progress counters [3][items], fail flag
+  int *h_started = nullptr;       // decoder: host-mapped count of resident cascade workgroups
+  int dec_side = 0;               // decoder: pooled side stream found to run beside the main stream
   DevBuf<long long> d_out3;
   bool coder_tables = false;
   struct EncOut { std::vector<unsigned char> bytes; int mapped = 0, maxbpn = 0; };
@@ -244,31 +241,26 @@ int sync_stream(sacamd_ctx *c) {
   return 0;
 }
 
-PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride, c->d_prof, c->d_olskeep.p, nullptr, nullptr, c->lane && c->tail_prio}; }
+PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_stride, c->d_prof, c->d_olskeep.p}; }
 
 // Streams are a per-DEVICE pool, shared by every context on the device and never destroyed.  The hardware runs a
 // limited number of queues at once (oversubscribing them makes the queue scheduler time-slice long kernels, which was
-// measured as an 11x slowdown with three contexts of 42 private streams each), so the pool holds 28 streams in all:
-//   normal set:  main + 8 (OLS capacity classes) + 4 (cascade launches) + 1 (marker)           = 14
-//   two high-priority sets (own hardware queues):  main + 3 (OLS) + 3 (cascade)                =  7 each
-// Contexts that keep several batches in flight (one host thread each) interleave their search generations on the
-// normal set -- they are throughput-bound and would share the chip anyway -- while the tails of two batches run on
-// the two high-priority sets.  Work of different contexts on one stream is ordered by that stream, which only ever
-// over-synchronises; every cross-stream dependency is an event owned by the context that recorded it.
+// measured as an 11x slowdown with three contexts of 42 private streams each), so the pool holds 14 streams:
+// main + 8 (OLS capacity classes) + 4 (cascade launches) + 1 (marker).  Work of different contexts on one stream is
+// ordered by that stream, which only ever over-synchronises; every cross-stream dependency is an event owned by the
+// context that recorded it.
 struct DevStreams {
   bool ready = false;
   hipStream_t lo_main = nullptr, lo_cls[sacamd_ctx::kSide] = {};
-  hipStream_t hi_main[2] = {}, hi_cls[2][6] = {};
-  std::atomic<unsigned> tails{0};
   // One search at a time per device: a batch's search saturates the chip on its own, and two searches issued to the
-  // pooled streams would only queue behind each other's dependency chains.  What does overlap is the search of one
-  // context with the latency-bound TAIL of another (sacamd_encode_frames releases this before its tail).
+  // pooled streams would only queue behind each other's dependency chains.  What may overlap is the search of one
+  // context with the latency-bound tail of another (sacamd_encode_frames releases this before its tail).
   std::mutex search_mu;
 };
 DevStreams g_streams[64];
 std::mutex g_streams_mu;
 
-int ensure_dev_streams(int device, bool want_hi) {
+int ensure_dev_streams(int device) {
   std::lock_guard<std::mutex> lk(g_streams_mu);
   DevStreams &d = g_streams[device & 63];
   if (!d.ready) {
@@ -277,38 +269,13 @@ int ensure_dev_streams(int device, bool want_hi) {
       if (hipStreamCreate(&d.lo_cls[k]) != hipSuccess) return SACAMD_ERR_HIP;
     d.ready = true;
   }
-  // The two tail sets exist only on request (SACAMD_TAIL_HI=1) and have the DEFAULT priority unless
-  // SACAMD_POOL_PRIO=1.  Measured on MI355X: the mere existence of high-priority streams in the process slows EVERY
-  // kernel by 20-25 % (coder 3.05 -> 4.1 s, OLS 9.8 -> 13.1 s per step of the 64 x 4 s run), whichever stream it is on.
-  if (want_hi && !d.hi_main[0]) {
-    int prio_lo = 0, prio_hi = 0;
-    const char *e = std::getenv("SACAMD_POOL_PRIO");
-    if (!(e && e[0] == '1') || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { prio_lo = prio_hi = 0; }
-    for (int h = 0; h < 2; h++) {
-      if (hipStreamCreateWithPriority(&d.hi_main[h], hipStreamDefault, prio_hi) != hipSuccess) return SACAMD_ERR_HIP;
-      for (int k = 0; k < 6; k++)
-        if (hipStreamCreateWithPriority(&d.hi_cls[h][k], hipStreamDefault, prio_hi) != hipSuccess) return SACAMD_ERR_HIP;
-    }
-  }
   return 0;
 }
 
-// make a stream set the active one: lane 0 = normal, lane 1 = the next high-priority set in rotation.  In a
-// high-priority set the logical slots alias 7 physical streams: the final pass only launches the promoted OLS classes
-// 2 / 5 / 6 / 7 (build_items) and the three canonical cascade classes.  The caller has synchronised the current set.
-void set_lane(sacamd_ctx *c, int lane) {
+void bind_streams(sacamd_ctx *c) {
   DevStreams &d = g_streams[c->device & 63];
-  c->lane = lane;
-  if (!lane) {
-    c->stream = c->own_main ? c->own_main : d.lo_main;
-    for (int k = 0; k < sacamd_ctx::kSide; k++) c->cls_stream[k] = d.lo_cls[k];
-    return;
-  }
-  const int h = (int)(d.tails.fetch_add(1) & 1);
-  c->stream = d.hi_main[h];
-  for (int k = 0; k < kNumOlsClasses; k++) c->cls_stream[k] = d.hi_cls[h][k <= 2 ? 0 : (k <= 5 ? 1 : 2)];
-  for (int q = 0; q < 4; q++) c->cls_stream[kNumOlsClasses + q] = d.hi_cls[h][3 + q % 3];
-  c->cls_stream[sacamd_ctx::kSide - 1] = d.hi_main[h];       // the marker only orders events
+  c->stream = c->own_main ? c->own_main : d.lo_main;
+  for (int k = 0; k < sacamd_ctx::kSide; k++) c->cls_stream[k] = d.lo_cls[k];
 }
 
 // ------------------------------------------------------------ work-item construction
@@ -337,10 +304,6 @@ int build_items(sacamd_ctx *c, const std::vector<Cand> &cands, std::vector<WorkI
         if (p.vn[s] < 1 || p.vn[s] > (8192 >> s)) return fail(c, SACAMD_ERR_ARG, "NLMS stage length outside the profile box");
       it.ols_class = 0;
       while (p.n_ols > kOlsClassMax[it.ols_class]) it.ols_class++;
-      // The final pass (latency-bound, one work-item per frame x channel) uses the capacity classes 32, 56, 64 and 96 taps
-      // only, so that its OLS kernels need three streams, not eight (see DevStreams; the 64 / 96-tap kernels hold one
-      // workgroup per CU and share a stream)
-      if (!cd.optimize && c->tail_hi) it.ols_class = it.ols_class <= 2 ? 2 : (it.ols_class <= 5 ? 5 : it.ols_class);
       const int *vn = p.vn;
       it.lms_class = lms_class_for(vn, /*canon=*/!cd.optimize);   // the final pass (k = 1, what the decoder recomputes) sums in slmath::dot order
       it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab; it.off_tabc = -1;
@@ -459,16 +422,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   }
   for (int i = 0; i < count; i++) if (ols_lead[i] != i) { items[i].off_pin = items[ols_lead[i]].off_pin; items[i].pin_kept = items[ols_lead[i]].pin_kept; }
   for (int i = 0; i < count; i++) items[i].ols_item = ols_lead[i];
-  // Final pass: the cascade of an item does not wait for the whole OLS launch -- it runs at the same time and follows
-  // its OLS stage chunk by chunk through a progress counter (both are latency-bound and sit on different SIMDs), so the
-  // pass costs max(OLS, cascade) instead of their sum.
-  const bool chase = want_pred && c->chase && !c->ols_keep_on;
   PcmView pv = view(c);
-  if (chase) {
-    HIPCHK(c, c->d_progress.ensure((size_t)count + 2));
-    HIPCHK(c, hipMemsetAsync(c->d_progress.p, 0, sizeof(int) * ((size_t)count + 2), c->stream));
-    pv.progress = c->d_progress.p; pv.started = c->d_progress.p + count;
-  }
   if (want_pred) HIPCHK(c, c->d_pred.ensure((size_t)tot_p + 512));
   HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
@@ -551,7 +505,9 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     {
       double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
-      Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
+      // statistics slot: the final pass runs its 33..64-tap items on the four-wave panel kernels (launch_ols), the search on the
+      // one-wave kernels: two kernel instances of one capacity class -> slots 8 + k for the former
+      Trace tr(c, st, "ols", (want_pred && k >= 3 && k <= 6) ? 8 + k : k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
       launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, want_pred);
     }
     HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
@@ -560,74 +516,20 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, hipEventRecord(sp_ols.b, c->cls_stream[kMark]));
   HIPCHK(c, hipEventRecord(c->ev_join[kMark], c->cls_stream[kMark]));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[kMark], 0));
-  // chase mode: the cascade kernels must not take the CUs before every OLS workgroup is resident (they would wait for
-  // producers that cannot start).  The OLS workgroups count themselves in; the host launches the cascade once all have
-  // begun -- or, if that does not happen within a second, falls back to ordering by the OLS completion events.
-  bool chasing = false;
-  if (chase) {
-    int n_ols_wg = 0;
-    for (int k = 0; k < kNumOlsClasses; k++) n_ols_wg += (int)idx_ols[k].size();
-    hipStream_t probe = g_streams[c->device & 63].lo_cls[sacamd_ctx::kSide - 1];   // a stream nothing long ever runs on
-    for (int tries = 0; tries < 2000 && !chasing; tries++) {
-      int begun = 0;
-      HIPCHK(c, hipMemcpyAsync(&begun, c->d_progress.p + count, sizeof(int), hipMemcpyDeviceToHost, probe));
-      HIPCHK(c, hipStreamSynchronize(probe));
-      if (begun >= n_ols_wg) chasing = true; else usleep(500);
-    }
-  }
-  PcmView pvl = pv;
-  if (!chasing) { pvl.progress = nullptr; pvl.started = nullptr; }
   bool lms_used[sacamd_ctx::kSide] = {};
-  auto launch_one = [&](size_t q, const PcmView &pvq) -> int {
+  auto launch_one = [&](size_t q) -> int {
     const LmsLaunch &ll = lms_launches[q];
     const int si = kNumOlsClasses + (int)(q % kLmsStreams);
     hipStream_t st = c->cls_stream[si];
     if (!lms_used[si]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); lms_used[si] = true; }
-    if (!chasing)
-      for (int k = ll.group ? kFastOls : 0; k < (ll.group ? kNumOlsClasses : kFastOls); k++)
+    for (int k = ll.group ? kFastOls : 0; k < (ll.group ? kNumOlsClasses : kFastOls); k++)
         if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
     double isteps = 0, fl = 0; for (int i = 0; i < ll.count; i++) if (flat[ll.first + i] >= 0) { isteps += items[flat[ll.first + i]].n; fl += lms_flops(items[flat[ll.first + i]]); }
     Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps, fl);
-    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, pvq, c->d_tab.p, c->d_p.p, c->d_q.p);
+    launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, pv, c->d_tab.p, c->d_p.p, c->d_q.p);
     return 0;
   };
-  // Final pass: a layout whose workgroup needs a whole CU's registers (the four-round canonical class) can only start
-  // on a CU that has drained completely; launched together with the two-per-CU layouts its work-items would start
-  // tens of seconds late and become the tail of the pass.  So per OLS group: wait (host) for the group's OLS kernels,
-  // launch the whole-CU layouts, wait until all their workgroups have begun (they count themselves in), then the rest.
-  std::vector<char> launched(lms_launches.size(), 0);
-  if (want_pred && !chasing && c->big_first) {
-    if (!chase) HIPCHK(c, c->d_progress.ensure((size_t)count + 2));      // (with chase requested the buffer exists and is in use)
-    hipStream_t probe = g_streams[c->device & 63].lo_cls[sacamd_ctx::kSide - 1];
-    HIPCHK(c, hipMemsetAsync(c->d_progress.p + count + 1, 0, sizeof(int), probe));
-    HIPCHK(c, hipStreamSynchronize(probe));
-    int expected = 0;
-    for (int g = 0; g < 2; g++) {
-      std::vector<size_t> big, rest;
-      for (size_t q = 0; q < lms_launches.size(); q++)
-        if (lms_launches[q].group == g) (lms_max_wg_per_cu(lms_launches[q].cls) == 1 ? big : rest).push_back(q);
-      if (big.empty() || rest.empty()) continue;
-      for (int k = g ? kFastOls : 0; k < (g ? kNumOlsClasses : kFastOls); k++)
-        if (!idx_ols[k].empty()) HIPCHK(c, hipEventSynchronize(c->ev_ols[k]));
-      PcmView pvb = pvl;
-      pvb.started = c->d_progress.p + count + 1;
-      for (size_t q : big) {
-        for (int i = 0; i < lms_launches[q].count; i++) if (flat[lms_launches[q].first + i] >= 0) expected++;
-        int r = launch_one(q, pvb); if (r) return r;
-        launched[q] = 1;
-      }
-      for (int tries = 0; tries < 4000; tries++) {       // <= 2 s; on timeout the rest is launched anyway
-        int begun = 0;
-        HIPCHK(c, hipMemcpyAsync(&begun, c->d_progress.p + count + 1, sizeof(int), hipMemcpyDeviceToHost, probe));
-        HIPCHK(c, hipStreamSynchronize(probe));
-        if (begun >= expected) break;
-        usleep(500);
-      }
-      for (size_t q : rest) { int r = launch_one(q, pvl); if (r) return r; launched[q] = 1; }
-    }
-  }
-  for (size_t q = 0; q < lms_launches.size(); q++)
-    if (!launched[q]) { int r = launch_one(q, pvl); if (r) return r; }
+  for (size_t q = 0; q < lms_launches.size(); q++) { int r = launch_one(q); if (r) return r; }
   for (int si = kNumOlsClasses; si < kMark; si++)
     if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], c->cls_stream[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
   HIPCHK(c, hipEventRecord(sp_lms.b, c->stream));
@@ -685,21 +587,17 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   sacamd_ctx *c = new sacamd_ctx();
   c->device = device; c->nch = nch; c->max_framesize = max_framesize; c->max_frames = max_frames;
   { const char *e = std::getenv("SACAMD_TRACE"); c->tracing = e && e[0] == '1'; }
-  { const char *e = std::getenv("SACAMD_TAIL_HI"); if (e) c->tail_hi = e[0] != '0'; }
-  if (ensure_dev_streams(device, c->tail_hi != 0) != 0) { delete c; return SACAMD_ERR_HIP; }
+  if (ensure_dev_streams(device) != 0) { delete c; return SACAMD_ERR_HIP; }
   // every context has its own main stream: generations of different contexts must not queue behind each other's
   // serial bias / cost / copy phases (they share the pooled side streams, where the heavy kernels run)
   if (hipStreamCreate(&c->own_main) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
-  { const char *e = std::getenv("SACAMD_TAIL_HI"); if (e) c->tail_hi = e[0] != '0'; }
-  { const char *e = std::getenv("SACAMD_CHASE"); if (e) c->chase = e[0] != '0'; }
-  { const char *e = std::getenv("SACAMD_BIG_FIRST"); if (e) c->big_first = e[0] != '0'; }
-  { const char *e = std::getenv("SACAMD_TAIL_PRIO"); if (e) c->tail_prio = e[0] != '0'; }
-  set_lane(c, 0);
+  bind_streams(c);
+  // (every failure below goes through sacamd_ctx_destroy, which releases whatever has been created so far)
   for (int k = 0; k < sacamd_ctx::kSide; k++)
-    if (hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
-  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) != hipSuccess) { sacamd_ctx_destroy(c); return SACAMD_ERR_HIP; }
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { sacamd_ctx_destroy(c); return SACAMD_ERR_HIP; }
   for (int k = 0; k < kNumOlsClasses; k++)
-    if (hipEventCreateWithFlags(&c->ev_ols[k], hipEventDisableTiming) != hipSuccess) { delete c; return SACAMD_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_ols[k], hipEventDisableTiming) != hipSuccess) { sacamd_ctx_destroy(c); return SACAMD_ERR_HIP; }
   c->ch_stride = ((long long)max_framesize + 63) / 64 * 64;
   c->frame_stride = c->ch_stride * nch;
   const size_t tot = (size_t)c->frame_stride * max_frames;
@@ -725,11 +623,11 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
-  c->d_pred.release(); c->d_nf.release(); c->d_progress.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
+  c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();
-  c->d_rj.release(); c->d_prefix.release(); c->d_tmp_s2u.release(); c->d_tmp_mb.release(); c->d_out3.release();
+  c->d_rj.release(); c->d_declink.release(); c->d_decprog.release(); if (c->h_started) (void)hipHostFree(c->h_started); c->d_prefix.release(); c->d_tmp_s2u.release(); c->d_tmp_mb.release(); c->d_out3.release();
   delete c;
 }
 
@@ -1144,12 +1042,12 @@ API int sacamd_eval_stats(sacamd_ctx *c, long long *out2, int reset) {
 }
 
 API int sacamd_class_times(sacamd_ctx *c, double *out, int cap, int reset) {
-  if (!c || !out || cap < (kNumOlsClasses + sacamd_ctx::kClsMax) * 4) return SACAMD_ERR_ARG;
+  if (!c || !out || cap < 2 * sacamd_ctx::kClsMax * 4) return SACAMD_ERR_ARG;
   collect_spans(c);
   static_assert(kNumOlsClasses == 8 && kNumLmsClasses <= sacamd_ctx::kClsMax, "sacamd_class_times layout");
   for (int kind = 0; kind < 2; kind++)
-    for (int k = 0; k < (kind ? sacamd_ctx::kClsMax : kNumOlsClasses); k++) {
-      double *o = out + (kind * kNumOlsClasses + k) * 4;
+    for (int k = 0; k < sacamd_ctx::kClsMax; k++) {
+      double *o = out + (kind * sacamd_ctx::kClsMax + k) * 4;
       o[0] = c->cls_ms[kind][k]; o[1] = (double)c->cls_launches[kind][k]; o[2] = c->cls_item_steps[kind][k]; o[3] = c->cls_flops[kind][k];
       if (reset) { c->cls_ms[kind][k] = 0; c->cls_launches[kind][k] = 0; c->cls_item_steps[kind][k] = 0; c->cls_flops[kind][k] = 0; }
     }
@@ -1173,3 +1071,4 @@ API int sacamd_kernel_times(sacamd_ctx *c, double *out16, int reset) {
 }
 
 #include "host_encode.inc"
+#include "host_decode.inc"

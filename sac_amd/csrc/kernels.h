@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "params.h"
+#include "simt.h"
 
 namespace sacamd {
 
@@ -11,11 +12,6 @@ struct PcmView {            // centred planar int32 PCM of the staged batch
   long long frame_stride, ch_stride;
   unsigned long long *prof;   // optional: 8 section cycle counters of the OLS kernel (debug)
   double *keep;               // kept p_lpc streams of earlier search generations (WorkItem::pin_kept), nullable
-  int *progress;              // final pass only (else null): per work-item count of p_lpc samples the OLS kernel has produced; the
-                              // cascade kernel of the item runs at the same time and follows it chunk by chunk
-  int *started;               // with progress: number of OLS workgroups that have begun (the host launches the cascade after all have)
-  int hiprio;                 // 1: latency-bound launch (final pass): its waves raise their issue priority (s_setprio) so that
-                              // throughput work sharing the CU (another batch's search) fills the gaps instead of slowing them
 };
 
 // ---- analyse (kernels_misc.hip)
@@ -36,6 +32,14 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
                 const double *d_tab, const double *d_p /*p_lpc in*/, double *d_q /*p_lpc+p_lms out*/);
 void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
                  const double *d_p, int *d_err, int *d_pred /*nullable*/, int *d_nonfinite /*[count]: set to 1 where the prediction was not finite*/);
+// ---- decoder: the three stages of every channel running side by side, two launches per group of frames (kernels_pred.hip)
+int dec_lms_class_for(const int *vn);            // cascade layout class of a decoder work-item (256-lane layouts only)
+size_t dec_cascade_lds_bytes(int lms_class, const LmsRingCap &rc);
+void launch_dec_cascade(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, size_t lds_bytes, LmsRingCap rc, PcmView v,
+                        const double *d_tab, const double *d_p, double *d_q, const DecLink *d_links, int *d_started /*host-visible*/);
+void launch_dec_olsbias(hipStream_t s, const WorkItem *d_items, const int *d_idx, int n_ols, int n_bias, bool any_wide, PcmView v, double *d_p, const double *d_q,
+                        const FrameStatsD *d_stats, int nch, const DecLink *d_lk_ols, const DecLink *d_lk_bias);
+void launch_used_prefix(hipStream_t s, int count, const unsigned char *d_used, const long long *d_off_used, int *d_prefix);
 // ---- costs / s2u (kernels_misc.hip)
 void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_off, const int *d_n, int count,
                  int *d_hist_scratch, double *d_cost);
@@ -54,8 +58,18 @@ struct CoderJob {
 };
 void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map /*jobs with_map*/, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv,
-                  unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len, int hiprio = 0);
+                  unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len);
 size_t coder_state_bytes();
+struct DecJob {
+  long long off_in;     // bytes into d_in (the channel's payload)
+  long long off_out;    // ints into d_err
+  int inlen, n, maxbpn;
+  int with_map;         // 1: the payload starts with the MapEncoder header; the decoded flags go to d_used + off_used
+  long long off_used;
+};
+void launch_decoder(hipStream_t s, const DecJob *d_jobs, int count, const unsigned char *d_in, int *d_err /*signed (mapped) residuals*/, unsigned char *d_used,
+                    const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv,
+                    unsigned char *d_state, size_t state_stride, int *d_consumed);
 struct RemapJob {
   long long off;        // ints into pred / err / s2u_map planes
   long long off_used;   // bytes into d_used

@@ -23,9 +23,8 @@ size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
 
 __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJob *jobs, int count, const int *s2u, const int *s2u_map, const unsigned char *used,
                                                const unsigned short *laplace, const short *gfwd, const unsigned short *ginv,
-                                               unsigned char *state, size_t stride, unsigned char *out, int *len, int hiprio) {
+                                               unsigned char *state, size_t stride, unsigned char *out, int *len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (hiprio) __builtin_amdgcn_s_setprio(3);
   CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
   coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
@@ -48,7 +47,7 @@ __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJo
 
 void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv, unsigned char *d_state,
-                  size_t state_stride, unsigned char *d_out, int *d_len, int hiprio) {
+                  size_t state_stride, unsigned char *d_out, int *d_len) {
   if (count <= 0) return;
   {   // per DEVICE opt-in to > 64 KB dynamic LDS (idempotent; launchers may be called from several host threads)
     static std::atomic<unsigned long long> done{0};
@@ -69,7 +68,57 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   if (count > 512) { spw = 3; while (spw < kCoderStreamsPerWg && count > 256 * spw) spw++; }
   const int wgs = (count + spw - 1) / spw;
   hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_s2u_map, d_used, d_laplace,
-                     d_fwd, d_inv, d_state, state_stride, d_out, d_len, hiprio);
+                     d_fwd, d_inv, d_state, state_stride, d_out, d_len);
+}
+
+// ------------------------------------------------------------------ entropy DEcoder (FrameCoder::DecodeMonoFrame, libsac.cpp:280-298)
+// one wave per stream: [MapEncoder::Decode ->] BitplaneCoder::Decode -> U2S; output = the signed residual (mapped residual
+// for mapped streams) in `err`, the decoded used-value flags in `used`
+__global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_decoder(const DecJob *jobs, int count, const unsigned char *in, int *err, unsigned char *used,
+                                                 const unsigned short *laplace, const short *gfwd, const unsigned short *ginv,
+                                                 unsigned char *state, size_t stride, int *consumed) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
+  coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, (int)blockDim.x);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const int ji = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+  if (ji >= count) return;                       // no further workgroup-wide barriers below
+  const DecJob job = jobs[ji];
+  char *sb = smem + CoderLdsLayout::o_stream + (size_t)wave * CoderLdsLayout::s_total;
+  CoderModel &M = *reinterpret_cast<CoderModel *>(sb + CoderLdsLayout::s_model);
+  CoderWin &W = *reinterpret_cast<CoderWin *>(sb + CoderLdsLayout::s_win);
+  MapModel &MM = *reinterpret_cast<MapModel *>(sb + CoderLdsLayout::s_map);
+  CntL *csig0 = reinterpret_cast<CntL *>(state + (size_t)ji * stride);
+  const unsigned short *plap = laplace + (size_t)kLaplacePlanes * kLaplaceAvg;
+  ExecDevWave ex;
+  int *dst = err + job.off_out;
+  const int used_bytes = coder_stream_dec(ex, in + job.off_in, job.inlen, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace,
+                                          plap, csig0, dst, M, T, W, MM);
+  const int l = threadIdx.x & 63;
+  for (int i = l; i < job.n; i += 64) { const int v = dst[i]; dst[i] = (v & 1) ? ((v + 1) >> 1) : -(v >> 1); }   // MathUtils::U2S (utils.h:268-273)
+  if (l == 0) consumed[ji] = used_bytes;
+}
+
+void launch_decoder(hipStream_t s, const DecJob *d_jobs, int count, const unsigned char *d_in, int *d_err, unsigned char *d_used,
+                    const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv, unsigned char *d_state,
+                    size_t state_stride, int *d_consumed) {
+  if (count <= 0) return;
+  {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      if (hipFuncSetAttribute((const void *)k_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CoderLdsLayout::bytes(kCoderStreamsPerWg)) != hipSuccess) return;
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  int spw = 1;
+  if (count > 512) { spw = 3; while (spw < kCoderStreamsPerWg && count > 256 * spw) spw++; }
+  const int wgs = (count + spw - 1) / spw;
+  hipLaunchKernelGGL(k_decoder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_in, d_err, d_used, d_laplace,
+                     d_fwd, d_inv, d_state, state_stride, d_consumed);
 }
 
 // ------------------------------------------------------------------ remap

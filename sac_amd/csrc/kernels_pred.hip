@@ -80,13 +80,10 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  if (v.hiprio) __builtin_amdgcn_s_setprio(3);
   double *out = (it.pin_kept ? v.keep : pbuf) + it.off_pin;   // off_pin: where this item's p_lpc lives
-  int *prog = v.progress ? v.progress + idx[blockIdx.x] : nullptr;
-  if (v.started && threadIdx.x == 0) atomicAdd(v.started, 1);
-  if constexpr (NL == 64) ols_stage_reg<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
-  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
-  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof, prog);
+  if constexpr (NL == 64) ols_stage_reg<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
+  else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
+  else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
 }
 
 template <int NL, int NMAX>
@@ -180,9 +177,7 @@ __global__ __launch_bounds__(LmsCfg<CLS>::NL, LmsCfg<CLS>::MINB) void k_lms(cons
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   ExecDev<NL> ex;
-  if (v.hiprio) __builtin_amdgcn_s_setprio(3);
-  if (v.started && !v.progress && threadIdx.x == 0) atomicAdd(v.started, 1);    // "this workgroup has begun" (host.hip: whole-CU layouts first)
-  lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof, v.progress ? v.progress + it.ols_item : nullptr, it.off_tabc >= 0 ? tab + it.off_tabc : nullptr);
+  lms_stage<ExecDev<NL>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, p, sp, tab + it.off_tab, self, it.n, (it.pin_kept ? v.keep : pbuf) + it.off_pin, qbuf + it.off_p, smem, rc.c, v.prof, nullptr, it.off_tabc >= 0 ? tab + it.off_tabc : nullptr);
 }
 
 template <int CLS>
@@ -276,7 +271,6 @@ __global__ __launch_bounds__(64) void k_bias(const WorkItem *items, int count, P
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= count) return;
-  if (v.hiprio) __builtin_amdgcn_s_setprio(3);
   const WorkItem &it = items[i];
   const ChanParam p = it.p;
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
@@ -290,6 +284,111 @@ void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, c
   if (count <= 0) return;
   const size_t bytes = (size_t)64 * kBiasSlabStride * sizeof(double);
   hipLaunchKernelGGL(k_bias, dim3((count + 63) / 64), dim3(64), bytes, s, d_items, count, v, d_stats, nch, d_p, d_err, d_pred, d_nonfinite);
+}
+
+// ------------------------------------------------------------------ decoder: the three stages of a channel side by side
+// FrameCoder::UnpredictFrame (libsac.cpp:144-199): a sample is only known once it has been predicted, so the stages cannot
+// run one after the other as in the encoder.  Each stage keeps its body (k = 1, canonical order) and all of them -- for both
+// channels of a frame -- run AT THE SAME TIME, handing values over sample by sample through release / acquire counters in
+// global memory (DecLink, simt.h).  Concurrent kernels need concurrent hardware queues, of which HIP maps only a few (and
+// which streams share one is not ours to choose), so the whole group is TWO launches: k_dec_cascade (every cascade layout
+// behind one entry point, one workgroup per channel) and k_dec_olsbias (OLS workgroups, then bias workgroups).  The host
+// launches only as many frames at once as are certainly co-resident, and every wait is bounded: a missing partner ends
+// in an error, not in a hang.
+constexpr int kDecThreads = 256;
+int dec_lms_class_for(const int *vn) {        // layouts of 256 lanes only (one block size for the whole launch)
+  if (canon3_fits(vn, LmsP17::c0, 2)) return 10;
+  if (canon3_fits(vn, LmsP33::c0, 2)) return 11;
+  if (canon3_fits(vn, LmsP49::c0, 2)) return 12;
+  return 9;
+}
+template <int CLS>
+static __device__ __forceinline__ void dec_cascade_role(const WorkItem &it, const int *self, const double *tab, const double *pbuf, double *qbuf, char *smem,
+                                                         const LmsRingCap &rc, const DecLink *link) {
+  using C = typename LmsCfg<CLS>::C;
+  double sp[4];
+  for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
+  ExecDev<kDecThreads> ex;
+  lms_stage<ExecDev<kDecThreads>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, it.p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_pin, qbuf + it.off_p, smem, rc.c, nullptr,
+                                                                                link, it.off_tabc >= 0 ? tab + it.off_tabc : nullptr);
+}
+__global__ __launch_bounds__(kDecThreads, 1) void k_dec_cascade(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf,
+                                                                 LmsRingCap rc, const DecLink *links, int *started) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ii = idx[blockIdx.x];
+  const WorkItem &it = items[ii];
+  const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+  if (threadIdx.x == 0) { __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // "resident" (host-visible counter)
+  switch (it.lms_class) {
+    case 10: dec_cascade_role<10>(it, self, tab, pbuf, qbuf, smem, rc, links + ii); break;
+    case 11: dec_cascade_role<11>(it, self, tab, pbuf, qbuf, smem, rc, links + ii); break;
+    case 12: dec_cascade_role<12>(it, self, tab, pbuf, qbuf, smem, rc, links + ii); break;
+    default: dec_cascade_role<9>(it, self, tab, pbuf, qbuf, smem, rc, links + ii); break;
+  }
+}
+size_t dec_cascade_lds_bytes(int lms_class, const LmsRingCap &rc) { return lms_lds_bytes(lms_class, rc); }
+void launch_dec_cascade(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, size_t lds_bytes, LmsRingCap rc, PcmView v,
+                        const double *d_tab, const double *d_p, double *d_q, const DecLink *d_links, int *d_started) {
+  if (count <= 0) return;
+  static std::atomic<unsigned long long> done{0};
+  if (ensure_dyn_lds((const void *)k_dec_cascade, 160 * 1024, done) != hipSuccess) return;
+  hipLaunchKernelGGL(k_dec_cascade, dim3(count), dim3(kDecThreads), lds_bytes, s, d_items, d_idx, v, d_tab, d_p, d_q, rc, d_links, d_started);
+}
+
+// blocks [0, n_ols): the OLS stage of item idx[b] (one wave up to 64 taps -- the other three waves leave at once -- four waves
+// beyond); blocks [n_ols, n_ols + n_bias): the bias stage of item idx[b] (one lane)
+__global__ __launch_bounds__(kDecThreads) void k_dec_olsbias(const WorkItem *items, const int *idx, int n_ols, PcmView v, double *pbuf, const double *qbuf,
+                                                              const FrameStatsD *stats, int nch, const DecLink *lk_ols, const DecLink *lk_bias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ii = idx[blockIdx.x];
+  const WorkItem &it = items[ii];
+  if ((int)blockIdx.x < n_ols) {
+    const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+    const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
+    if (it.p.n_ols <= 64) {
+      if (threadIdx.x >= 64) return;
+      ExecDev<64> ex;
+      ols_stage_reg<ExecDev<64>, 64>(ex, it.p, self, other, it.n, pbuf + it.off_pin, smem, nullptr, lk_ols + ii);
+    } else {
+      ExecDev<256> ex;
+      ols_stage_panel2<ExecDev<256>, 96>(ex, it.p, self, other, it.n, pbuf + it.off_pin, smem, nullptr, lk_ols + ii);
+    }
+  } else {
+    if (threadIdx.x != 0) return;                         // one scalar recurrence: a wave of them would wait for each other's partners
+    const int mean = stats[it.frame * nch + it.ch_self].mean;
+    bias_stage(it.p, nullptr, it.n, qbuf + it.off_p, mean, nullptr, nullptr, reinterpret_cast<double *>(smem), nullptr, lk_bias + ii);
+  }
+}
+void launch_dec_olsbias(hipStream_t s, const WorkItem *d_items, const int *d_idx, int n_ols, int n_bias, bool any_wide, PcmView v, double *d_p, const double *d_q,
+                        const FrameStatsD *d_stats, int nch, const DecLink *d_lk_ols, const DecLink *d_lk_bias) {
+  if (n_ols + n_bias <= 0) return;
+  static std::atomic<unsigned long long> done{0};
+  if (ensure_dyn_lds((const void *)k_dec_olsbias, ols_panel2_lds_bytes(96), done) != hipSuccess) return;
+  const size_t bytes = any_wide ? ols_panel2_lds_bytes(96) : OlsLdsFast::bytes(64);
+  hipLaunchKernelGGL(k_dec_olsbias, dim3(n_ols + n_bias), dim3(kDecThreads), bytes, s, d_items, d_idx, n_ols, v, d_p, d_q, d_stats, nch, d_lk_ols, d_lk_bias);
+}
+
+// prefix[j] = number of used values in [-32768, -32768 + j - 1], j = 0 .. 65537 (Remap::isUsed: 0 is always used), one block per job
+__global__ __launch_bounds__(256) void k_used_prefix(const unsigned char *used, const long long *off_used, int *prefix) {
+  __shared__ int part[256];
+  const unsigned char *u = used + off_used[blockIdx.x];
+  int *pf = prefix + (size_t)blockIdx.x * 65540;
+  auto flag = [&](int v) { return v == 0 ? 1 : (v > 0 ? (int)u[32769 + v] : (int)u[-v]); };
+  constexpr int N = 65537, PER = (N + 255) / 256;
+  const int j0 = threadIdx.x * PER, j1 = (j0 + PER < N) ? j0 + PER : N;
+  int loc = 0;
+  for (int j = j0; j < j1; j++) loc += flag(j - 32768);
+  part[threadIdx.x] = loc;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; i++) { const int t = part[i]; part[i] = run; run += t; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int j = j0; j < j1; j++) { pf[j] = run; run += flag(j - 32768); }
+  if (j1 == N && j0 < N) pf[N] = run;
+}
+void launch_used_prefix(hipStream_t s, int count, const unsigned char *d_used, const long long *d_off_used, int *d_prefix) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_used_prefix, dim3(count), dim3(256), 0, s, d_used, d_off_used, d_prefix);
 }
 
 }  // namespace sacamd

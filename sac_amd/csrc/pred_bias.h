@@ -20,8 +20,29 @@ constexpr int kBiasSlabDoubles = 2 * kBiasCtx + 12;   // {cnt,val} pairs + 4x3 S
 // tables: this lane's slab of kBiasSlabDoubles doubles.  err/pred may be null.  *nonfinite (nullable) is set to 1
 // when a prediction is not finite -- where the reference throws (pred/cascade.h:40-41) the caller reports
 // SACAMD_ERR_NONFINITE (final pass) or an infinite cost (search).
+// Remap::Unmap (map.cpp:189-202) with prefix counts instead of the value-by-value walk: the smallest step err >= 1 in the
+// direction of merr's sign such that exactly |merr| used values lie in (pred, pred + err]; 0 and everything the walk would
+// never leave (no such step) -> the walk's bound.  prefix[j] = #used values in [-32768, -32768 + j - 1], j = 0 .. 65537.
+SA_HD int bias_unmap(const int *prefix, int pred, int merr) {
+  if (merr == 0) return 0;
+  const int sgn = merr < 0 ? -1 : 1, m = merr < 0 ? -merr : merr;
+  auto cnt = [&](int a, int b) {          // used values in [a, b]
+    a = a < -32768 ? -32768 : a; b = b > 32768 ? 32768 : b;
+    return a > b ? 0 : prefix[b + 32768 + 1] - prefix[a + 32768];
+  };
+  int lo = 1, hi = 1 << 17;               // smallest e with count(e) >= m (the count grows by at most one per step)
+  while (lo < hi) {
+    const int e = (lo + hi) >> 1;
+    const int c = sgn > 0 ? cnt(pred + 1, pred + e) : cnt(pred - e, pred - 1);
+    if (c >= m) hi = e; else lo = e + 1;
+  }
+  return sgn * lo;
+}
+
+// dec != null: decoder (FrameCoder::UnpredictFrame's dprocess, libsac.cpp:153-165): the sample is the prediction plus the
+// decoded residual (un-mapped first for mapped streams), written to dec->self_w and announced; `self` is not read.
 SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *psum, int mean,
-                      int *err, int *pred, double *tables, int *nonfinite = nullptr) {
+                      int *err, int *pred, double *tables, int *nonfinite = nullptr, const DecLink *dec = nullptr) {
   double *cnt = tables, *val = tables + kBiasCtx;
   for (int i = 0; i < kBiasCtx; i++) { cnt[i] = 4.0; val[i] = 0.0; }
   double *mixw = tables + 2 * kBiasCtx;    // [4][3]
@@ -33,6 +54,7 @@ SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *
   const double mu = p.bias_mu;
 
   for (int t = 0; t < n; t++) {
+    if (dec && !sa_wait_ge(dec->prog_in, t + 1, dec->fail)) return;
     const double px = psum[t];
     if (nonfinite && !(fabs(px) <= 1.79769313486231570815e308)) *nonfinite = 1;
     // CalcContext (bias.h:64-113)
@@ -59,8 +81,14 @@ SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *
     const double pbias = dot_canon(pt, mw, 3);
     const double pd = px + pbias;
     // eprocess (libsac.cpp:105-109)
-    const int v = self[t];
     const int pi = clampi32((int)round(pd), p.out_lo, p.out_hi);
+    int v;
+    if (dec) {
+      const int e = dec->merr[t];
+      v = pi + (dec->prefix ? bias_unmap(dec->prefix, pi + mean, e) : e);
+      dec->self_w[t] = v;
+      sa_publish(dec->prog_out, t + 1);
+    } else v = self[t];
     if (pred) pred[t] = pi + mean;
     if (err) err[t] = v - pi;
     // Update (bias.h:127-163)

@@ -214,7 +214,7 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
 template <class E, class C, int CANON = 0, int ROUNDS = 1>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
                      const int *self, int n, const double *pin_g, double *pout_g, char *lds_base, const int *ringcap,
-                     unsigned long long *prof = nullptr, const int *progress = nullptr, const double *tabc = nullptr) {
+                     unsigned long long *prof = nullptr, const DecLink *dec = nullptr, const double *tabc = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
   constexpr int kLmsChunk = NL;   // samples staged per global<->LDS exchange: one element per lane
@@ -363,12 +363,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
 
   for (int t0 = 0; t0 < n; t0 += kLmsChunk) {
     // ---- stage a chunk of p_lpc / target in, flush the previous chunk of p_lpc+p_lms out
-    if (progress) {   // the OLS stage of this item is still running (final pass): wait until it has produced the chunk
-      const int need = t0 + kLmsChunk < n ? t0 + kLmsChunk : n;
-      ex.par([&](int l) { if ((l & 63) == 0) while (sa_acquire(progress) < need) sa_backoff(); });
-      ex.sync();
-    }
-    ex.par([&](int l) {
+    if (!dec) ex.par([&](int l) {      // (decoder: inputs arrive and outputs leave sample by sample, see the head below)
       if (t0 > 0) pout_g[t0 - kLmsChunk + l] = L.pout[l];
       if (t0 + l < n) { L.pin[l] = pin_g[t0 + l]; L.sv[l] = self[t0 + l]; }
     });
@@ -715,9 +710,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       });
       ex.wsync();
       double bp[5] = {0, 0, 0, 0, 0};
+      bool dec_ok = true;
       ex.wave(0, [&]() {
-        const double plpc = L.pin[tt];
-        const double target = (double)L.sv[tt] - plpc;
         const double smw0 = L.hs[12], smw1 = L.hs[13];
         // Cascade::Predict (cascade.h:93-100)
         const double rpx = L.hs[10];                       // dot(rx, rw), left here by wave 2 after its update
@@ -726,7 +720,22 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         pl[4] = rpx;
         for (int e = 0; e < 2; e++) ep[e] = dot_canon_n<5>([&](int i) { return pl[i]; }, [&](int i) { return L.exwm[5 * e + i]; });
         const double pred = dot_canon_n<2>([&](int i) { return i ? ep[1] : ep[0]; }, [&](int i) { return i ? smw1 : smw0; });
-        L.pout[tt] = plpc + pred;
+        // The OLS prediction joins here; then the target of all updates, val - p_lpc (pred.cpp:43).  Decoder: p_lpc comes from
+        // the OLS kernel of this channel running beside this one, the sum goes to the bias kernel, whose decoded sample comes back.
+        double plpc, target;
+        if (!dec) {
+          plpc = L.pin[tt];
+          L.pout[tt] = plpc + pred;
+          target = (double)L.sv[tt] - plpc;
+        } else {
+          const int t = t0 + tt;
+          dec_ok = sa_wait_ge(dec->prog_in, t + 1, dec->fail);
+          plpc = pin_g[t];
+          if (E::is_lane0()) { pout_g[t] = plpc + pred; sa_publish(dec->prog_out, t + 1); }
+          dec_ok = dec_ok && sa_wait_ge(dec->prog_self, t + 1, dec->fail);
+          target = (double)self[t] - plpc;
+          if (!dec_ok && E::is_lane0()) L.hs[15] = 1.0;       // a partner kernel is not there: everybody leaves after the barrier
+        }
         // Cascade::Update(target): stage targets (cascade.h:101-112)
         double p_prefix = 0.0;
 #pragma unroll
@@ -748,6 +757,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       // gains (all the next sweep needs from it); waves 1..3 run, beside it, the three updates that only
       // feed the NEXT prediction, so that after barrier 2 all four waves start the next sweep together.
       ex.sync();
+      if (dec && L.hs[15] != 0.0) return;
       // ---- wave 1: LS_ADA experts (ls.h:224-236), lanes 0..9: expert e = l/5 (0: L1 loss, 1: L2), input i = l%5
       ex.wave_par(1, [&](int g) {
         const int l = g & 63;
@@ -841,7 +851,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[8 + i] = tp[i]; });
 #undef SA_TICK
   // flush the last chunk
-  ex.par([&](int l) {
+  if (!dec) ex.par([&](int l) {
     const int t0 = ((n - 1) / kLmsChunk) * kLmsChunk;
     if (n > 0 && t0 + l < n) pout_g[t0 + l] = L.pout[l];
   });

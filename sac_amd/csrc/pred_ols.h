@@ -116,221 +116,13 @@ struct OlsLdsFast {
   }
 };
 
-// One wave, lane l <-> row l of the covariance / L (n_ols <= 64).  The factorisation is the
-// reference's own left-looking loop nest (math.h:21-73): column j's chains for all rows i >= j run
-// in parallel across lanes, each lane walking k = 0..j-1 in order with its own L[i][k] (one
-// coalesced LDS read per k: column k is contiguous in the packed triangle) and row j's L[j][k]
-// (same-address broadcast read).  The reciprocal of pivot j-1 is issued before column j's first
-// j-1 terms, which do not need it, and consumed for the last term.
-template <class E, int NMAX>
-SA_HD void ols_stage_fast(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                          double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
-  static_assert(E::nl == 64, "one-wave path");
-  constexpr int nmax = NMAX;
-  constexpr int S = NMAX + kOlsPad;   // column stride of Lq (rows NMAX.. are zero padding)
-  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
-#define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
-  constexpr int NL = 64;
-  const int no = p.n_ols;
-  const int ntri = tri_count(no);
-  OlsLdsFast L;
-  L.carve(lds_base, nmax);
-  const unsigned long long *exptab = reinterpret_cast<const unsigned long long *>(L.libm + 128 * 3);
-
-  typename E::template Reg<double> xr, breg, wreg, sreg, zreg, areg, invd_mine, acc, accprev, dacc;
-  typename E::template Reg<int> xnext;
-
-  ex.par([&](int l) {
-    xr[l] = 0.0; breg[l] = 0.0; wreg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; areg[l] = 0.0; invd_mine[l] = 0.0; acc[l] = 0.0; accprev[l] = 0.0; dacc[l] = 0.0;
-    if (l < no) L.X[l] = 0.0;
-    for (int e = l; e < NMAX + kOlsPad; e += NL) { L.Wv[e] = 0.0; L.Dv[e] = 0.0; }
-    for (int e = l; e < ntri; e += NL) L.M[e] = 0.0;
-    for (int e = l; e < NMAX * S; e += NL) L.Lq[e] = 0.0;
-    sa_stage_tables(L.libm, l, NL);
-    xnext[l] = (l < no && n > 0) ? ols_x(p, self, other, n, 0, l) : 0;
-  });
-  ex.sync();
-
-  double esum = 0.0;
-  int km = 0;
-  const double lambda = p.lambda, nu = p.nu_eff;
-  const double one_m_lambda = 1.0 - lambda;
-
-  if (prof) tc = E::clock();
-  int sv_ahead = n > 0 ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
-  for (int t = 0; t < n; t++) {
-    const int sv = sv_ahead;
-    if (t + 1 < n) sv_ahead = self[t + 1];
-    ex.par([&](int l) {
-      xr[l] = (double)xnext[l];
-      if (l < no) L.X[l] = xr[l];
-      if (l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
-    });
-    ex.sync();
-    double pred = 0.0, val = 0.0, ff = 0.0;
-    // slmath::dot with its eight FMA accumulators spread over lanes (lane a runs accumulator a & 7)
-    ex.par([&](int l) {
-      const int a = l & 7;
-      double c = 0.0;
-      for (int i = 0; i + 8 <= no; i += 8) c = fma(L.X[i + a], L.Wv[i + a], c);
-      dacc[l] = c;
-    });
-    ex.uni([&]() {
-      pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
-      val = (double)sv;
-      const double e = val - pred;
-      esum = fma(p.beta_sum, esum, fabs(e));
-      const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
-      ff = one_m_lambda * c;
-    });
-    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
-    SA_TICK(0);
-    // covariance / rhs update (ols.cpp:38-45): lane = row i, loop over columns j <= i
-    ex.par([&](int l) {
-      if (l < no) {
-        const double xi = xr[l];
-        int j = 0;
-        // loads are unconditional (rows above the diagonal read harmless neighbours of the packed
-        // triangle), only the stores are masked
-        double *dump = L.dump;                       // write-only slot
-        for (; j + 8 <= no; j += 8) {
-          double m[8], xj[8];
-          int e[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) { e[u] = tri_off(no, j + u) + (l - (j + u)); xj[u] = L.X[j + u]; m[u] = L.M[e[u]]; }
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const double v = fma(lambda, m[u], ff * (xi * xj[u]));
-            double *dst = (l >= j + u) ? &L.M[e[u]] : dump;      // select the address, not the lane
-            *dst = v;
-          }
-        }
-        for (; j < no; j++) { const int e = tri_off(no, j) + (l - j); const double v = fma(lambda, L.M[e], ff * (xi * L.X[j])); if (l >= j) L.M[e] = v; }
-        breg[l] = fma(lambda, breg[l], ff * (xi * val));
-      }
-    });
-    SA_TICK(1);
-    km++;
-    if (km >= p.k) {
-      km = 0;
-      // ---- LDL^T, left-looking.  Each lane only re-reads M elements it wrote itself.
-      // Lanes that own no row of the current column run the same arithmetic on harmless values
-      // (no exec-mask churn); only stores are masked.  Column offsets advance incrementally:
-      // off(k+1) = off(k) + (no - k).
-      bool ok = true;
-      double dprev = 0.0, invd_prev = 0.0;
-      int oj = 0;                                   // tri_off(no, j)
-      ex.par([&](int l) { sreg[l] = breg[l]; });    // forward substitution starts from b
-      // Column j's stored-column terms k = 0 .. j-2 run as whole 8-term chunks.  D[k] is published
-      // one column late (D[j-1] in column j's finish phase) and D is cleared first, so the chunk
-      // terms k >= j-1 multiply by D[k] == 0 and leave the chain untouched; no tail masks.
-      ex.par([&](int l) { for (int e = l; e < NMAX + kOlsPad; e += NL) L.Dv[e] = 0.0; });
-      ex.wsync();
-      for (int j = 0; j < no; j++) {
-        double dj = 0.0;
-        const int nchunk = (j + 6) >> 3;            // ceil((j-1)/8); 8*nchunk <= NMAX
-        ex.par([&](int l) {
-          const int li = l < S ? l : S - 1;          // idle lanes read a padding row
-          const int lm = l < no ? l : no - 1;
-          double s_ = L.M[oj + (lm - j)];
-          if (l == j) s_ = s_ + nu;
-          const double *pa = L.Lq + li;               // own row: element k at pa[k*S]
-          const double *pb = L.Lq + j;                // row j (same address in all lanes)
-          struct Fc { double a[8], b[8], d[8]; };
-          auto ld = [&](Fc &c, int m) {
-            const int k = 8 * m;
-#pragma unroll
-            for (int u = 0; u < 8; u++) { c.a[u] = pa[(k + u) * S]; c.b[u] = pb[(k + u) * S]; c.d[u] = L.Dv[k + u]; }
-          };
-          auto ac = [&](double v, const Fc &c) {
-            double td[8];                             // the 16 products are independent of the chain: issue them first
-#pragma unroll
-            for (int u = 0; u < 8; u++) td[u] = c.a[u] * c.b[u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) td[u] = td[u] * c.d[u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v = v - td[u];   // k <= j-2: never the fused term
-            return v;
-          };
-          if (nchunk > 0) {
-            Fc A, B;
-            ld(A, 0);
-            int m = 0;
-            while (true) {                            // double-buffered: chunk m+1 loads under chunk m's chain
-              if (m + 1 < nchunk) ld(B, m + 1);
-              s_ = ac(s_, A);
-              if (++m >= nchunk) break;
-              if (m + 1 < nchunk) ld(A, m + 1);
-              s_ = ac(s_, B);
-              if (++m >= nchunk) break;
-            }
-          }
-          acc[l] = s_;
-        });
-        if (j > 0) {
-          // finish column j-1: L[i][j-1] = lij * invD (math.h:49); its last term for column j.
-          // The forward substitution L y = b rides along: step j-1 of its column sweep needs exactly
-          // this column (still in registers) and y[j-1], which is final by now (math.h:58-66).
-          const double yk = ex.lane_bcast(sreg, j - 1);
-          ex.par([&](int l) {
-            const double lp = accprev[l] * invd_prev;
-            accprev[l] = lp;
-            if (l > j - 1 && l < no) L.Lq[(j - 1) * S + l] = lp;
-            if (l == 0) L.Dv[j - 1] = dprev;
-            const double v = fold_fused(j - 1, l) ? fma(-lp, yk, sreg[l]) : sreg[l] - lp * yk;
-            if (l > j - 1 && l < no) sreg[l] = v;
-          });
-          const double bj = ex.lane_bcast(accprev, j);
-          const bool fz = fold_fused(j - 1, j);
-          ex.par([&](int l) {
-            const double tt = accprev[l] * bj;
-            acc[l] = fz ? fma(-tt, dprev, acc[l]) : acc[l] - tt * dprev;
-          });
-        }
-        dj = ex.lane_bcast(acc, j);
-        if (dj < 1e-12) { ok = false; break; }
-        const double invd = 1.0 / dj;
-        ex.par([&](int l) {
-          if (l == j) invd_mine[l] = invd;
-          accprev[l] = acc[l];
-        });
-        dprev = dj; invd_prev = invd;
-        oj += no - j;
-        ex.wsync();   // one wave: LDS traffic is in order, only the compiler needs the fence
-      }
-      SA_TICK(2);
-      if (ok) {
-        // (the forward substitution was carried along by the factorisation)
-        ex.par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
-        SA_TICK(3);
-        // backward solve: row i is the fused chain z_i - L[i+1][i] w[i+1] - ... in that order
-        // (math.h:67-72).  Every lane walks the same chain with same-address (broadcast) LDS
-        // reads issued eight at a time; only the fma sits on the dependency chain.
-        ex.par([&](int l) { if (l < no) L.Dv[l] = zreg[l]; });     // z into LDS (D is no longer needed)
-        ex.wsync();
-        // One uniform instruction stream for all rows; row i runs ceil((no-1-i)/8) whole chunks
-        // starting at term i+1 (the rows >= no of column i and of w are zero padding).  w[i+1]
-        // is carried in a register; same-wave LDS traffic is ordered, so no fence between rows.
-        // Fully unrolled and anchored at the LAST row: with ip = no-1-i and kp = no-1-k the chain of
-        // row ip is  z'[ip] - sum_{kp = ip-1 .. 0} L'[ip][kp] w'[kp]  in exactly that order, so
-        // w' lives in registers under compile-time indices and every L element is one LDS read
-        // at a compile-time offset from a single base (no address arithmetic, no w re-reads).
-        ex.lane0([&]() {
-          double wr[NMAX];
-          const double *lb = L.Lq - (NMAX - no) * (S + 1);          // lb[(NMAX-1-ip)*S + (NMAX-1-kp)] == L[k][i]
-          const double *zb = L.Dv - (NMAX - no);                    // zb[NMAX-1-ip] == z[i]
-          double *wb = L.Wv - (NMAX - no);
-          OlsBwdRows<NMAX, S, 0>::run(no, L.X, lb, zb, wb, wr);
-        });
-        ex.wsync();
-        SA_TICK(4);
-      }
-    }
-    ex.sync();
-    SA_TICK(5);
-  }
-  if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[i] = tp[i]; });
-#undef SA_TICK
+// decoder: number of decoded samples of the OTHER channel the regressor of step t reads (0: none)
+SA_HD int ols_other_need(const ChanParam &p, int n, int t) {
+  if (p.b + p.c <= 0) return 0;
+  int u = t - p.du;
+  if (u < 0) u = 0;
+  const int need = u + p.c;                 // highest index read is u - b + (b + c - 1)
+  return need < n ? need : n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -420,7 +212,7 @@ struct OlsCovUpdate {
 
 template <class E, int NMAX>
 SA_HD void ols_stage_reg(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                         double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
+                         double *p_out, char *lds_base, unsigned long long *prof = nullptr, const DecLink *dec = nullptr) {
   static_assert(E::nl == 64 && NMAX <= 64 && NMAX % 4 == 0, "one-wave path");
   constexpr bool MREG = NMAX <= 32;         // covariance rows in registers (else: packed triangle in LDS)
   constexpr int S = NMAX + kOlsPad;
@@ -438,6 +230,7 @@ SA_HD void ols_stage_reg(E &ex, const ChanParam &p, const int *self, const int *
   typename E::template Reg<OlsRow<NMAX>> V;
   typename E::template Reg<int> xnext;
 
+  if (dec) sa_wait_ge(dec->prog_other, ols_other_need(p, n, 0), dec->fail);     // decoder: the first regressor may read the partner's first samples
   ex.par([&](int l) {
     xr[l] = 0.0; breg[l] = 0.0; sreg[l] = 0.0; zreg[l] = 0.0; invd_mine[l] = 0.0; lk[l] = 0.0; dacc[l] = 0.0;
 #pragma unroll
@@ -457,14 +250,14 @@ SA_HD void ols_stage_reg(E &ex, const ChanParam &p, const int *self, const int *
   const double one_m_lambda = 1.0 - lambda;
 
   if (prof) tc = E::clock();
-  int sv_ahead = n > 0 ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
+  int sv_ahead = (n > 0 && !dec) ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
   for (int t = 0; t < n; t++) {
-    const int sv = sv_ahead;
-    if (t + 1 < n) sv_ahead = self[t + 1];
+    int sv = sv_ahead;
+    if (!dec && t + 1 < n) sv_ahead = self[t + 1];
     ex.par([&](int l) {
       xr[l] = (double)xnext[l];
       if (l < no) L.X[l] = xr[l];
-      if (l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
+      if (!dec && l < no && t + 1 < n) xnext[l] = ols_x(p, self, other, n, t + 1, l);
     });
     ex.sync();
     double pred = 0.0, val = 0.0, ff = 0.0;
@@ -474,15 +267,19 @@ SA_HD void ols_stage_reg(E &ex, const ChanParam &p, const int *self, const int *
       for (int i = 0; i + 8 <= no; i += 8) c = fma(L.X[i + a], L.Wv[i + a], c);
       dacc[l] = c;
     });
+    ex.uni([&]() { pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no); });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; if (dec) sa_publish(dec->prog_out, t + 1); } });
+    if (dec) {         // decoder: the sample exists once the cascade and bias stages have added their part to this prediction
+      if (!sa_wait_ge(dec->prog_self, t + 1, dec->fail)) return;
+      sv = self[t];
+    }
     ex.uni([&]() {
-      pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
       val = (double)sv;
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
       ff = one_m_lambda * c;
     });
-    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
     SA_TICK(0);
     if constexpr (MREG) {
       OlsCovUpdate<NMAX, 0>::run(ex, no, M, xr, lambda, ff);
@@ -576,6 +373,10 @@ SA_HD void ols_stage_reg(E &ex, const ChanParam &p, const int *self, const int *
         SA_TICK(4);
       }
     }
+    if (dec && t + 1 < n) {      // decoder: the next regressor, now that this channel's sample t (and the partner's share) exists
+      if (!sa_wait_ge(dec->prog_other, ols_other_need(p, n, t + 1), dec->fail)) return;
+      ex.par([&](int l) { if (l < no) xnext[l] = ols_x(p, self, other, n, t + 1, l); });
+    }
     ex.sync();
     SA_TICK(5);
   }
@@ -600,7 +401,7 @@ template <int N> struct OlsArr { double v[N]; };
 
 template <class E, int NMAX>
 SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                           double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
+                           double *p_out, char *lds_base, unsigned long long *prof = nullptr) {
   constexpr int NL = E::nl;
   constexpr int PW = NL / 64;
   static_assert(PW == 4 || PW == 8, "panel width = number of waves");
@@ -666,7 +467,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
       ff = one_m_lambda * c;
     });
-    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; } });
     ex.sync();
     SA_TICK(0);
     // covariance / rhs update (ols.cpp:38-45): lane = row, wave w takes the column groups 8w, 8w+8*PW, ..
@@ -824,7 +625,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
 // becomes a pair, broadcasts pick the half that owns the row.  One workgroup (four waves) per CU.
 template <class E, int NMAX>
 SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const int *other, int n,
-                            double *p_out, char *lds_base, unsigned long long *prof = nullptr, int *progress = nullptr) {
+                            double *p_out, char *lds_base, unsigned long long *prof = nullptr, const DecLink *dec = nullptr) {
   constexpr int NL = E::nl;
   constexpr int PW = NL / 64;
   static_assert(PW == 4 && NMAX > 64 && NMAX <= 128, "four waves, two rows per lane");
@@ -846,6 +647,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
   struct I2 { int v[2]; };
   typename E::template Reg<I2> xnext;
 
+  if (dec) sa_wait_ge(dec->prog_other, ols_other_need(p, n, 0), dec->fail);     // decoder: the first regressor may read the partner's first samples
   ex.par([&](int l) {
     for (int h = 0; h < 2; h++) {
       xr[l].v[h] = 0.0; breg[l].v[h] = 0.0; sreg[l].v[h] = 0.0; zreg[l].v[h] = 0.0; invd_mine[l].v[h] = 0.0; accc[l].v[h] = 0.0; lpc[l].v[h] = 0.0;
@@ -870,10 +672,10 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
   const double one_m_lambda = 1.0 - lambda;
 
   if (prof) tc = E::clock();
-  int sv_ahead = n > 0 ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
+  int sv_ahead = (n > 0 && !dec) ? self[0] : 0;              // this step's sample, fetched one step ahead (the load is off the chain)
   for (int t = 0; t < n; t++) {
-    const int sv = sv_ahead;
-    if (t + 1 < n) sv_ahead = self[t + 1];
+    int sv = sv_ahead;
+    if (!dec && t + 1 < n) sv_ahead = self[t + 1];
     ex.par([&](int l) {
       if (l < 64) {
 #pragma unroll
@@ -881,7 +683,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
           const int row = l + 64 * h;
           xr[l].v[h] = (double)xnext[l].v[h];
           if (row < no) L.X[row] = xr[l].v[h];
-          if (row < no && t + 1 < n) xnext[l].v[h] = ols_x(p, self, other, n, t + 1, row);
+          if (!dec && row < no && t + 1 < n) xnext[l].v[h] = ols_x(p, self, other, n, t + 1, row);
         }
       }
     });
@@ -893,15 +695,20 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
       for (int i = 0; i + 8 <= no; i += 8) c = fma(L.X[i + a], L.Wv[i + a], c);
       dacc[l] = c;
     });
+    ex.leader([&]() { pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no); });
+    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; if (dec) sa_publish(dec->prog_out, t + 1); } });
+    if (dec) {         // decoder: see ols_stage_reg
+      if (!sa_wait_ge(dec->prog_self, t + 1, dec->fail)) return;
+      sv = self[t];
+    }
     ex.leader([&]() {
-      pred = ols_dot_finish(ex, dacc, L.X, L.Wv, no);
       val = (double)sv;
       const double e = val - pred;
       esum = fma(p.beta_sum, esum, fabs(e));
       const double c = sa_pow_t(esum + p.beta_add, -p.beta_pow, L.libm, exptab);
       ff = one_m_lambda * c;
     });
-    ex.par([&](int l) { if (l == 0) { p_out[t] = pred; sc[0] = ff; if (progress && (((t + 1) & 127) == 0 || t + 1 == n)) sa_publish(progress, t + 1); } });
+    ex.par([&](int l) { if (l == 0) sc[0] = ff; });
     ex.sync();
     SA_TICK(0);
     // covariance / rhs update: lane = rows r, r+64; wave w takes the column groups 8w, 8w+32, ..
@@ -1067,6 +874,15 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
         ex.wsync();
         SA_TICK(4);
       }
+    }
+    if (dec && t + 1 < n) {
+      if (!sa_wait_ge(dec->prog_other, ols_other_need(p, n, t + 1), dec->fail)) return;
+      ex.par([&](int l) {
+        if (l < 64) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) { const int row = l + 64 * h; if (row < no) xnext[l].v[h] = ols_x(p, self, other, n, t + 1, row); }
+        }
+      });
     }
     ex.sync();
     SA_TICK(5);

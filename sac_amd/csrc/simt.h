@@ -57,6 +57,37 @@ SA_HD void sa_backoff() {
 #endif
 }
 
+// ---- decoder: per-sample hand-offs between the three stage kernels of a channel (and its stereo partner), which run at
+// the same time: the decoder only learns a sample after predicting it (FrameCoder::UnpredictFrame, libsac.cpp:144-199),
+// so the stages cannot run one after the other as in the encoder.  Counters are release-stored by their producer and
+// acquire-loaded by their consumers (agent scope); data is written before the counter and read after it.
+struct DecLink {
+  int *self_w;               // bias stage: the channel's decoded (centred) samples -- the `self` input of the other two
+  const int *prog_self;      // samples of this channel decoded so far
+  const int *prog_other;     // ... of the stereo partner (OLS regressor; == prog_self for mono)
+  const int *prog_in;        // values the upstream stage has produced (cascade: p_lpc; bias: p_lpc + p_lms)
+  int *prog_out;             // values this stage has produced (OLS: p_lpc; cascade: p_lpc + p_lms; bias: decoded samples)
+  int *fail;                 // set by whoever waited too long (a partner kernel is not running): all waits end
+  const int *merr;           // bias stage: the entropy-decoded (mapped) residuals
+  const int *prefix;         // bias stage, mapped streams: prefix[j] = number of used values in [-32768, -32768 + j - 1]; else null
+};
+// true when *p >= need; false when the link has failed (never blocks for more than ~2 s)
+SA_HD bool sa_wait_ge(const int *p, int need, int *fail) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (true) {
+    __builtin_amdgcn_s_sleep(8);
+    if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    if (__builtin_readcyclecounter() - t0 > 5000000000ull) { __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+  }
+#else
+  (void)fail;
+  return *p >= need;
+#endif
+}
+
 // ------------------------------------------------------------------ emulation executor
 template <int NL>
 struct ExecEmu {
@@ -73,6 +104,7 @@ struct ExecEmu {
   // code only wave 0 executes (uniformly): run once
   template <class F> void leader(F &&f) { f(); }
   void sync() {}
+  void gsync() {}     // sync() that also orders the group's GLOBAL memory traffic (stores visible to its own later loads)
   template <class T> T lane_get(const Reg<T> &r, int k) { return r[k]; }
   double lane_bcast(const Reg<double> &r, int k) { return r[k]; }
   template <class R> double lane_bcast_col(const R &r, int col, int k) { return r[k].v[col]; }   // element `col` of lane k's register array
@@ -272,6 +304,7 @@ struct ExecDevWave {
   };
   template <class F> SA_D void par(F &&f) { f((int)(threadIdx.x & 63)); }
   SA_D void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  SA_D void gsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
   SA_D void wsync() { sync(); }
   SA_D int lane_geti(const Reg<int> &r, int k) { return __builtin_amdgcn_readlane(r.v, k); }
   template <class F> SA_D void lane0(F &&f) { if ((threadIdx.x & 63) == 0) f(); }

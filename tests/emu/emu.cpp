@@ -146,6 +146,22 @@ API int emu_bitplane(const int32_t *s2u, int n, int maxbpn, const unsigned char 
   return len;
 }
 
+// decode side: bytes -> s2u values (+ used flags when with_map); returns bytes consumed
+API int emu_bitplane_decode(const unsigned char *in, int inlen, int n, int maxbpn, unsigned char *used_out, const int *fwd_i, const int *inv_i, int32_t *s2u) {
+  static std::vector<unsigned short> lap; static unsigned short plap[32];
+  if (lap.empty()) host_laplace(lap, plap);
+  std::vector<short> gf(kPScale); std::vector<unsigned short> gi(4095);
+  for (int i = 0; i < kPScale; i++) gf[i] = (short)fwd_i[i];
+  for (int i = 0; i < 4095; i++) gi[i] = (unsigned short)inv_i[i];
+  std::vector<CntL> csig0(65536);
+  CoderModel *M = new CoderModel; CoderTabs *T = new CoderTabs; CoderWin *W = new CoderWin; MapModel *MM = new MapModel;
+  ExecEmu<64> ex;
+  ex.par([&](int l) { coder_tabs_init(*T, gf.data(), gi.data(), l, 64); });
+  const int used = coder_stream_dec(ex, in, inlen, n, maxbpn, used_out, lap.data(), plap, csig0.data(), s2u, *M, *T, *W, *MM);
+  delete M; delete T; delete W; delete MM;
+  return used;
+}
+
 // ---------------------------------------------------------------- host DDS logic (product code) on a test function
 #include "../../sac_amd/csrc/dds_host.h"
 API double emu_dds_quadratic(int ndim, const double *xmin, const double *xmax, const double *xstart, const double *center,

@@ -332,3 +332,36 @@ def test_register_resident_ols_kernel_body_vs_oracle(emu, orc, nA, nM0, opt):
     pd, ol, om, oe = orc.predict_trace(smp, stats, g, 0, n, opt)
     assert np.array_equal(plpc.view(np.uint64), ol.view(np.uint64))
     assert np.array_equal(err, oe) or opt          # search evaluations: free-order cascade sums (tolerance elsewhere)
+
+
+def test_decoder_body_emulated_inverts_the_golden_streams(emu, orc, golden):
+    """The entropy-DEcoder kernel body (coder_stream_dec: RangeCoderSH::DecodeBitOne + BitplaneCoder::Decode [+ MapEncoder::
+    Decode], vle.cpp:233-261, map.cpp:87-101) turns the genuine reference's bytes back into the s2u values / used flags."""
+    fwd, inv = orc.domain_tables()
+    u = np.ascontiguousarray(golden["coder/s2u"], np.int32)
+    mb = int(golden["coder/maxbpn"][0])
+    payload = np.ascontiguousarray(golden["coder/bytes"], np.uint8)
+    out = np.zeros(u.size, np.int32)
+    used = emu.emu_bitplane_decode(_vp(payload), payload.size, u.size, mb, None, _vp(fwd), _vp(inv), _vp(out))
+    assert np.array_equal(out, u)
+    assert used <= payload.size + 4          # the decoder reads up to four bytes past the flush (BufIO's zero fill)
+    # mapped stream of the golden sparse frame: map header + remapped residual
+    raw = golden["frame/sparse16_normal/raw"][0]
+    smp, stats = center_frame(raw[None, :])
+    err, pred = orc.predict_frame(smp, stats, golden["profile"][:, 2].copy(), 0, raw.size, 0)
+    r, s2m, mbm, ul, uh = orc.remap(raw, pred[0], err[0])
+    payload = np.ascontiguousarray(np.frombuffer(golden["frame/sparse16_normal/record"].tobytes()[4 + 232 + 18:], np.uint8))
+    out = np.zeros(s2m.size, np.int32); flags = np.zeros(2 * 32769, np.uint8)
+    emu.emu_bitplane_decode(_vp(payload), payload.size, s2m.size, mbm, _vp(flags), _vp(fwd), _vp(inv), _vp(out))
+    assert np.array_equal(out, s2m)
+    assert np.array_equal(flags[:32769], ul) and np.array_equal(flags[32769:], uh)
+    # random residuals, ragged lengths (chunk boundaries, n < 64, single sample)
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 63, 64, 65, 127, 129, 1000):
+        e = np.rint(rng.laplace(size=n) * rng.choice([1, 20, 3000])).astype(np.int32)
+        u = np.where(e < 0, -2 * e, np.where(e > 0, 2 * e - 1, 0)).astype(np.int32)
+        mb = max(int(u.max()).bit_length() - 1, 0)
+        payload = np.ascontiguousarray(np.frombuffer(orc.bitplane_encode(u, mb), np.uint8))
+        out = np.zeros(n, np.int32)
+        emu.emu_bitplane_decode(_vp(payload), payload.size, n, mb, None, _vp(fwd), _vp(inv), _vp(out))
+        assert np.array_equal(out, u), n

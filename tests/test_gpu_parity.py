@@ -551,26 +551,56 @@ def test_framecoder_wrapper_warm_start_chain(api, golden_r3, tmp_path, name):
     ctx.close()
 
 
-@pytest.mark.parametrize("env", [{"SACAMD_CHASE": "1"}, {"SACAMD_TAIL_HI": "1"}, {"SACAMD_TAIL_HI": "1", "SACAMD_TAIL_PRIO": "1"}])
-def test_optional_schedules_write_the_same_records(api, golden, tmp_path, env):
-    """The schedules that are off by default -- cascade chasing the OLS stage through progress counters,
-    the tail on its own stream sets with promoted OLS capacity classes, raised wave priority -- change WHEN kernels run,
-    never what they compute: same records as the genuine reference (a fresh process per setting: the switches are read
-    when a context is created)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np\n"
-        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
-        "import sac_amd.api as api\n"
-        "from golden_cases import FRAMESIZE, frame_cases\n"
-        f"g = np.load({os.path.join(root, 'tests', 'golden', 'ref_golden.npz')!r})\n"
-        "for name in ('s16_high_mt4', 'sparse16s_normal', 'm16_normal'):\n"
-        "    raw = g[f'frame/{name}/raw']; cfg = frame_cases()[name][1]\n"
-        "    ctx = api.Context(raw.shape[0], FRAMESIZE, 1); ctx.upload_i32([raw], FRAMESIZE)\n"
-        "    c = api.Cfg(cfg.optimize, cfg.sparse_pcm, cfg.zero_mean, cfg.reset, cfg.fraction, cfg.maxnfunc, cfg.num_threads, cfg.sigma, cfg.optk, cfg.cost)\n"
-        "    recs, _ = ctx.encode_frames(c); ctx.close()\n"
-        "    assert recs[0] == g[f'frame/{name}/record'].tobytes(), name\n"
-        "print('SCHEDULE_OK')\n")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
-    assert r.returncode == 0 and "SCHEDULE_OK" in r.stdout, r.stderr[-2000:]
+def test_gpu_decoder_inverts_the_reference_records(api, golden, golden_r3):
+    """SURVEY 8f rank 4: ReadEncoded + Decode (RangeCoderSH + [MapEncoder +] BitplaneCoder::Decode) + UnpredictFrame on the GPU:
+    every golden frame record of the GENUINE reference (mono / stereo, 8-bit, sparse-PCM mapped streams, raw un-centred input,
+    a 40-sample frame, silence, DDS-chosen profiles, warm-start chains) decodes to the PCM it was made from, bit for bit."""
+    for name, (_, cfg) in frame_cases().items():
+        raw = golden[f"frame/{name}/raw"]
+        rec = golden[f"frame/{name}/record"].tobytes()
+        ctx = api.Context(raw.shape[0], FRAMESIZE, 1)
+        pcm, prof = ctx.decode_frames([rec], FRAMESIZE)
+        ctx.close()
+        assert np.array_equal(pcm[0], raw), name
+        assert np.array_equal(prof[0], golden[f"frame/{name}/profile"]), name
+    # several frames in one call (ragged lengths do not occur within a file's channel count; the chain frames are equal-sized)
+    for name, (frames, cfg) in chain_cases().items():
+        raws = [golden_r3[f"chain/{name}/{f}/raw"].astype(np.int32) for f in range(len(frames))]
+        recs = [golden_r3[f"chain/{name}/{f}/record"].tobytes() for f in range(len(frames))]
+        ctx = api.Context(raws[0].shape[0], FRAMESIZE, len(recs))
+        pcm, _ = ctx.decode_frames(recs, FRAMESIZE)
+        ctx.close()
+        for f in range(len(recs)):
+            assert np.array_equal(pcm[f], raws[f]), (name, f)
+
+
+def test_gpu_decoder_roundtrip_random_profiles_and_ragged_batch(api, orc):
+    """encode on the GPU -> decode on the GPU == input, and the GPU decoder == the CPU checker's decoder on the same records:
+    random profiles (long regressors up to 96 taps, every cascade layout), ragged frame lengths in one batch."""
+    P = api.default_profile()
+    rng = np.random.default_rng(77)
+    raws = [synth_pcm(n, 2, 500 + i, RATE) for i, n in enumerate([3000, 1, 777, 2048, 65])]
+    ctx = api.Context(2, FRAMESIZE, len(raws))
+    ctx.upload_i32(raws, FRAMESIZE)
+    profs = np.stack([rand_profile(P, rng, cap=False, scale=1.5) for _ in raws])
+    profs[1] = P[:, 2]
+    profs[3][[24, 9, 25, 26, 27]] = [32, 32, 32, 32, -32]          # 64 / 96-tap regressors, ch_ref swap
+    recs, _ = ctx.encode_frames(api.make_cfg("normal"), profiles=profs)      # optimize = 0: the given profiles are used as they are
+    pcm, prof = ctx.decode_frames(recs, FRAMESIZE)
+    ctx.close()
+    for f, raw in enumerate(raws):
+        assert np.array_equal(pcm[f], raw), f
+        dec, _ = orc.decode_frame(recs[f], 2, FRAMESIZE)
+        assert np.array_equal(dec, raw), f
+
+
+def test_gpu_decoder_full_size_frame(api, orc):
+    """One 882 000-sample stereo frame at the default profile through GPU encode -> GPU decode (lossless), and the decoded PCM of
+    the record equals the CPU checker's decode of it."""
+    raw = synth_pcm(20 * 44100, 2, 1000, 44100)
+    ctx = api.Context(2, FULL_FRAMESIZE, 1)
+    ctx.upload_i32([raw], FULL_FRAMESIZE)
+    recs, _ = ctx.encode_frames(api.make_cfg("normal"))
+    pcm, _ = ctx.decode_frames(recs, FULL_FRAMESIZE)
+    ctx.close()
+    assert np.array_equal(pcm[0], raw)
