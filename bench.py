@@ -9,8 +9,11 @@ range coding -> frame records on the host [-> RCCL gather to rank 0]) over one b
 16-bit / 44.1 kHz stereo frames, `--high` preset (fraction 0.1, 100 evaluations, sigma 0.2,
 entropy cost) with the search run as 8-candidate DDS generations and --opt-reset
 (== reference `--high --opt-cfg=dds,8 --opt-reset`).  Inputs (interleaved int16 PCM) are resident
-in HBM before the timed region starts.  Frames shard across ranks with no data-path collective
-(weak scaling: every GPU gets --frames frames); the only collective is the final record gather.
+in HBM before the timed region starts.  Frames shard across ranks with no data-path collective; the only collective
+is the end-of-step gather of the frame records to rank 0, done by the library (sacamd_gather_records: RCCL all-gather of the
+lengths + one group of ncclSend/ncclRecv; `--gather torch` selects a torch.distributed gather instead).
+--scaling weak (default): every GPU gets --frames frames.  --scaling strong: ONE corpus of --frames frames is split over
+the ranks by sacamd_assign_frames (cost-based, longest first).
 
 Every step stages the PCM again (which clears the library's per-batch memo of channel evaluations), so
 each step performs every distinct evaluation of its own search; nothing is carried from step to step.
@@ -62,15 +65,21 @@ def _synth_one(args):
     return synth_pcm(n, 2, seed=seed, rate=RATE)
 
 
-def make_batch(nframes, seconds, seed0):
+def make_batch(nframes, seconds, seed0, frame_ids=None):
     """nframes synthetic stereo frames (distinct seeds) -> (planar int32 frames, interleaved int16 [nframes*n, 2], n).
-    Synthesis is host work outside the timed region; it is spread over the host cores."""
+    Synthesis is host work outside the timed region; it is spread over the host cores.  frame_ids: the frames of a
+    corpus this rank owns (seed = seed0 + frame id); default 0..nframes-1."""
     n = int(seconds * RATE)
-    jobs = [(n, seed0 + i) for i in range(nframes)]
+    if frame_ids is None:
+        frame_ids = list(range(nframes))
+    nframes = len(frame_ids)
+    jobs = [(n, seed0 + i) for i in frame_ids]
     # synthesis takes a minute of host time (and crawls under rocprofv3, which traces the forked workers): keep the batch on
     # disk, keyed by what determines it, so that a profiled run after a plain one in the same session reuses it
     cache_dir = os.environ.get("SAC_BENCH_CACHE", "/tmp/sac_bench_cache")
-    cache = os.path.join(cache_dir, f"pcm_{nframes}x{n}_seed{seed0}.npy")
+    import hashlib
+    tag = "" if frame_ids == list(range(nframes)) else "_ids" + hashlib.sha1(repr(frame_ids).encode()).hexdigest()[:10]
+    cache = os.path.join(cache_dir, f"pcm_{nframes}x{n}_seed{seed0}{tag}.npy")
     if os.path.exists(cache):
         try:
             il = np.load(cache)
@@ -240,6 +249,10 @@ def main():
                     help="after the timed region decode this many seeded-random frame records of the last step with the CPU reference "
                          "decoder (oracle/_ref, else the oracle) and compare with the input PCM; 0 = off")
     ap.add_argument("--no-all-cores", action="store_true", help="skip the all-host-cores CPU figure")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("SAC_BENCH_SCALING", "weak"),
+                    help="weak: --frames frames per GPU; strong: one corpus of --frames frames split over the ranks by sacamd_assign_frames")
+    ap.add_argument("--gather", choices=("rccl", "torch"), default=os.environ.get("SAC_BENCH_GATHER", "rccl"),
+                    help="record gather to rank 0: the library's RCCL gather behind the C ABI (default) or torch.distributed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -252,7 +265,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
 
     # ---- host-side setup that must precede HIP initialisation (forks)
-    frames, il, n = make_batch(args.frames, args.seconds, seed0=1000 + 1000 * rank)
+    if args.scaling == "strong":
+        # one corpus of --frames frames; frame f has seed 1000 + f; owner by estimated cost C*(E*T_opt + T) (all frames of
+        # this synthetic corpus are equally long, so the library's longest-first rule deals them out evenly)
+        total_frames = args.frames
+        n_est = int(args.seconds * RATE)
+        cost = [2.0 * (100 * 0.1 * max(n_est, 20 * RATE if args.seconds >= 20 else n_est) + n_est)] * total_frames
+        my_ids = shard_frames(total_frames, rank, world, cost=cost)
+        frames, il, n = make_batch(len(my_ids), args.seconds, seed0=1000, frame_ids=my_ids)
+    else:
+        total_frames = args.frames * world
+        my_ids = [rank * args.frames + i for i in range(args.frames)]
+        frames, il, n = make_batch(args.frames, args.seconds, seed0=1000 + 1000 * rank)
+    nloc = len(my_ids)                                         # frames this rank encodes per step
     framesize = int(20 * RATE) if args.seconds >= 20 else n   # reference: max_framelen(20 s) * rate
 
     # ---- CPU baselines that fork (before HIP is initialised in this process): all host cores, one frame per process
@@ -276,6 +301,42 @@ def main():
 
     import sac_amd.api as api
 
+    # ---- communicator of the library's record gather (one RCCL rank per process); its unique id travels over the
+    # torch.distributed group that the launch contract provides anyway (barrier, max-over-ranks timing)
+    comm, gather_kind, gather_note = None, "none (1 rank)", None
+    if dist is not None:
+        gather_kind = "torch.distributed"
+        if args.gather == "rccl":
+            try:
+                idt = torch.zeros(api.COMM_ID_BYTES, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    idt = torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8).to(device)
+                dist.broadcast(idt, 0)
+                comm = api.Comm(local_rank, rank, world, bytes(idt.cpu().numpy().tobytes()))
+                ok = torch.tensor([1], dtype=torch.int32, device=device)
+            except Exception as e:       # reported in the line; the run goes on with the torch.distributed gather
+                gather_note = f"sacamd_comm_create failed on rank {rank}: {e}"
+                ok = torch.tensor([0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks use the same gather
+            if int(ok.item()) == 1:
+                gather_kind = "sacamd_gather_records (RCCL: ncclAllGather of lengths + grouped ncclSend/ncclRecv)"
+            else:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                gather_note = gather_note or "sacamd_comm_create failed on another rank"
+
+    def gather(recs):
+        if comm is not None:
+            return comm.gather_records(my_ids, recs, total_frames)
+        out = gather_records(recs, rank, world, device)       # rank-major order
+        if out is None or args.scaling != "strong":
+            return out
+        owner = api.assign_frames(cost, world)
+        order = [f for r in range(world) for f in range(total_frames) if owner[f] == r]
+        got = dict(zip(order, out))
+        return [got[f] for f in range(total_frames)]
+
     t_h2d = time.perf_counter()
     d_pcm = torch.from_numpy(il).to(device)            # interleaved L/R int16, resident in HBM
     torch.cuda.synchronize()
@@ -289,9 +350,9 @@ def main():
     # batch; the library lets one search run at a time per device.  Default depth 1: measured on MI355X the overlap does
     # not pay (a dependent fp64 chain already keeps its SIMD's issue port ~70 % busy).
     depth = max(1, args.pipeline)
-    ctxs = [api.Context(2, max(n, 16), args.frames, device=local_rank) for _ in range(depth)]
-    frame_off = np.arange(args.frames, dtype=np.int64) * n
-    nsamp = np.full(args.frames, n, np.int32)
+    ctxs = [api.Context(2, max(n, 16), max(nloc, 1), device=local_rank) for _ in range(depth)]
+    frame_off = np.arange(nloc, dtype=np.int64) * n
+    nsamp = np.full(nloc, n, np.int32)
     groups = [(c, frame_off, nsamp) for c in ctxs]     # (kept name: the statistics helpers below iterate over it)
 
     def barrier():
@@ -302,7 +363,7 @@ def main():
     def run_step(d, small=False):
         ctx = ctxs[d]
         if small:     # warm-up: first frames of the batch, 2 s each
-            k = min(args.frames, 8)
+            k = min(nloc, 8)
             ns = np.minimum(nsamp[:k], 2 * RATE).astype(np.int32)
             ctx.attach_s16_device(d_pcm.data_ptr(), frame_off[:k], ns, framesize)
         else:
@@ -379,7 +440,7 @@ def main():
                 state["error"] = e
                 lock.notify_all()
 
-    samples_per_step = args.frames * n * 2 * world
+    samples_per_step = total_frames * n * 2
     latest = {"line": None}
 
     def on_term(signum, frame):
@@ -395,16 +456,17 @@ def main():
         out = {
             "metric": "encode MSamples/s + bps, 16-bit/44.1kHz stereo, --high; 1/2/4/8 MI355X",
             "value": value, "unit": "MSamples/s", "n_gpus": world, "steps": nsteps, "steps_requested": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt * 1e3 / nsteps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt * 1e3 / nsteps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.frames} frames/GPU x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
+            "config": {"workload": f"{args.frames} frames{'/GPU' if args.scaling == 'weak' else ' in all, split over the GPUs'} x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
                                    f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
-                       "frames_per_gpu": args.frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
-                       "pipeline_depth": depth, "rccl_ranks": world,
-                       "parallelism": f"frames sharded over {world} GPU(s), RCCL record gather",
+                       "frames_per_gpu": nloc, "total_frames": total_frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
+                       "pipeline_depth": depth, "rccl_ranks": world if dist is not None else 1,
+                       "record_gather": gather_kind, "record_gather_note": gather_note,
+                       "parallelism": f"frames sharded over {world} GPU(s), record gather to rank 0 in frame order",
                        "warmup_batch": "min(8, frames of the group) frames x 2 s per group (code-object load only)",
                        "budget_s": args.budget_s},
-            "bps": bps, "x_realtime": (args.frames * world * args.seconds * nsteps) / dt,
+            "bps": bps, "x_realtime": (total_frames * args.seconds * nsteps) / dt,
             "complete": bool(final),
         }
         out["h2d"] = {"ms": t_h2d * 1e3, "bytes": int(il.nbytes), "in_timed_region": False,
@@ -430,7 +492,7 @@ def main():
         for (kind, cls), (ms, launches, isteps, flops) in ct.items():
             cands[kname(kind, cls)] = (ms, launches, STAGE_BYTES[kind] * isteps, isteps, flops)
         cands["k_coder"] = (kt["coder"]["ms"], max(kt["coder"]["launches"], 1),
-                            (4 + out["bps"] / 8) * n * 2 * args.frames * nsteps, 0.0, 0.0)
+                            (4 + out["bps"] / 8) * n * 2 * nloc * nsteps, 0.0, 0.0)
         # dominant kernel: the instance with the largest total launch time within the stage that spans most of the
         # step (launches of different classes overlap, so their times do not add up; the OLS stage span is the longest)
         fam = "k_ols" if kt["ols"]["ms"] >= max(kt["lms"]["ms"], kt["coder"]["ms"]) else ("k_lms" if kt["lms"]["ms"] >= kt["coder"]["ms"] else "k_coder")
@@ -510,7 +572,7 @@ def main():
             with lock:
                 state["planned"] = planned
                 lock.notify_all()
-        allrecs = gather_records(recs, rank, world, device) if dist is not None else recs
+        allrecs = gather(recs) if dist is not None else recs
         last_recs = recs
         nsteps = step + 1
         if nsteps >= state["planned"]:
@@ -546,6 +608,8 @@ def main():
             out["verified_frames"] = pick
             out["verified_with"] = "oracle/_ref decoder (genuine reference objects)" if ref_available() else "oracle restatement"
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,11 +32,13 @@ typedef enum sacamd_status {
   SACAMD_ERR_HIP = -2,      /* HIP runtime error (see sacamd_last_error) */
   SACAMD_ERR_NOGPU = -3,    /* no usable gfx950 device */
   SACAMD_ERR_STATE = -4,    /* call order violated (e.g. evaluate before analyse) */
-  SACAMD_ERR_NONFINITE = -5 /* a predictor produced a non-finite value (cascade.h:40-41) */
+  SACAMD_ERR_NONFINITE = -5,/* a predictor produced a non-finite value (cascade.h:40-41) */
+  SACAMD_ERR_COMM = -6      /* RCCL error in the record gather (see sacamd_comm_last_error) */
 } sacamd_status;
 
 /* FrameCoder::SearchCost / SearchMethod, libsac/libsac.h:14-15 */
 enum { SACAMD_COST_L1 = 0, SACAMD_COST_RMS = 1, SACAMD_COST_ENTROPY = 2, SACAMD_COST_GOLOMB = 3, SACAMD_COST_BITPLANE = 4 };
+enum { SACAMD_SEARCH_DDS = 0, SACAMD_SEARCH_DE = 1, SACAMD_SEARCH_CMA = 2 };
 
 /* FrameCoder::tsac_cfg + toptim_cfg (+ OptDDS::DDSCfg), libsac/libsac.h:19-44, opt/dds.h:12-19,
  * flattened.  Presets: cmdline.cpp:127-156. */
@@ -52,6 +54,10 @@ typedef struct sacamd_cfg {
   double sigma;      /* DDSCfg.sigma_init */
   int optk;          /* toptim_cfg.optk (default 4) */
   int optimize_cost; /* SACAMD_COST_* */
+  int optimize_search; /* toptim_cfg.optimize_search, SACAMD_SEARCH_*: --opt-cfg=dds|de|cma (cmdline.cpp:195-207).  DE
+                          (opt/de.cpp: population 30, current-to-pbest/1/bin) and CMA (opt/cma.cpp: (1+1)-CMA-ES) take
+                          maxnfunc and sigma as DDS does (cmdline.cpp:221-241); num_threads only sets how the reference
+                          spreads evaluations over threads and does not change their results.  (ABI version 3.) */
 } sacamd_cfg;
 
 typedef struct sacamd_ctx sacamd_ctx;
@@ -118,8 +124,8 @@ int sacamd_get_encoded(sacamd_ctx *ctx, int frame, int ch, uint8_t *out, int cap
 
 /* ---- (6) whole batch: Predict + Encode + WriteEncoded -------------------------------------
  * Replaces: the per-frame sequence FrameCoder::Predict(); Encode(); WriteEncoded()
- * (libsac.cpp:827-829, 443-479, 565-578) for every staged frame, including the DDS search
- * (opt/dds.cpp) run in lock-step generations across frames.
+ * (libsac.cpp:827-829, 443-479, 565-578) for every staged frame, including the search
+ * (opt/dds.cpp, opt/de.cpp or opt/cma.cpp by cfg.optimize_search) run in lock-step generations across frames.
  * profiles_io [nframes][58]: in = search start point per frame (cfg.reset!=0: ignored, the base
  * profile is used, == --opt-reset); out = profile written into each record.
  * out receives the frame records back to back; rec_off[f]..rec_off[f+1] delimit frame f. */
@@ -127,7 +133,7 @@ int sacamd_encode_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles
                          long long cap, long long *rec_off /* [nframes+1] */);
 
 /* The search alone.  Replaces: FrameCoder::Optimize (libsac.cpp:365-427, called from Predict, :461-476) with OptDDS
- * (opt/dds.cpp) for every staged frame.  profiles_io [nframes][58]: in = start point (ignored with cfg.reset != 0),
+ * (opt/dds.cpp), OptDE (opt/de.cpp:77-164) or OptCMA (opt/cma.cpp:49-92) for every staged frame.  profiles_io [nframes][58]: in = start point (ignored with cfg.reset != 0),
  * out = the profile the search settled on.  Follow with sacamd_predict_final + sacamd_encode for the
  * Predict() / Encode() split of the reference's FrameCoder (sac_amd/csrc/framecoder.h). */
 int sacamd_search_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles_io);
@@ -159,9 +165,46 @@ int sacamd_decode_frames(sacamd_ctx *ctx, int nframes, int framesize, const uint
 /* ---- multi-GPU sharding (host only) ----------------------------------------------------------
  * Frames are independent units (with cfg.reset): owner[f] = rank that encodes frame f, assigned longest-first by the
  * caller's cost estimate (channels * (evaluations * search window + frame length)) to the least loaded of `world`
- * ranks.  Each rank stages its frames, runs sacamd_encode_frames and sends its records to rank 0 (the only
- * communication on this path; bench.py: gather_records over torch.distributed == RCCL). */
+ * ranks.  Each rank stages its frames, runs sacamd_encode_frames and sends its records to rank 0 with
+ * sacamd_gather_records (the only communication on this path). */
 int sacamd_assign_frames(const double *cost, int nframes, int world, int *owner);
+
+/* ---- multi-GPU record gather (RCCL over xGMI) ----------------------------------------------------
+ * Replaces: nothing in the single-process reference; what is gathered is what FrameCoder::WriteEncoded
+ * (libsac.cpp:565-578) appends to the file, frame after frame, in Codec::EncodeFile's loop (:822-829) -- rank 0 ends up with
+ * the records of all ranks in frame order and writes them behind the header exactly as the reference does.
+ * One process per GPU.  Rank 0 calls sacamd_comm_unique_id and hands the 128 bytes to the other ranks by whatever
+ * means the launcher offers (bench.py: the torch.distributed store); every rank then calls sacamd_comm_create
+ * (ncclCommInitRank) for its device.  sacamd_gather_records is collective: every rank passes its nrec records
+ * (back to back in recs, rec_off[i]..rec_off[i+1] delimit record i, as sacamd_encode_frames writes them) with their
+ * global frame numbers frame_id[i]; the ranks' frame ids must partition 0..total_frames-1.  Rank 0 receives all
+ * records in frame order in out (capacity cap bytes) with out_off[total_frames+1]; other ranks may pass NULL / 0.
+ * Wire traffic: one all-gather of (count, bytes), one all-gather of (frame, length) pairs, then ONE group of
+ * ncclSend / ncclRecv (rank 0 posts a receive per peer inside a single ncclGroupStart/End, so its xGMI links fill
+ * concurrently); payloads are staged through device buffers owned by the communicator. */
+typedef struct sacamd_comm sacamd_comm;
+#define SACAMD_COMM_ID_BYTES 128
+int sacamd_comm_unique_id(uint8_t *id128);
+int sacamd_comm_create(int device, int rank, int world, const uint8_t *id128, sacamd_comm **out);
+void sacamd_comm_destroy(sacamd_comm *comm);
+const char *sacamd_comm_last_error(const sacamd_comm *comm);
+int sacamd_gather_records(sacamd_comm *comm, int nrec, const int *frame_id, const uint8_t *recs, const long long *rec_off,
+                          int total_frames, uint8_t *out, long long cap, long long *out_off);
+/* The same gather over a caller-supplied transport (host buffers): MPI in a host application; the gloo transport of this
+ * repository's CPU tests.  allgather_i64: recv[r*count + i] = rank r's send[i].  send / recv between group_begin and
+ * group_end may complete as late as group_end; all of them are complete when group_end returns.  Callbacks return 0
+ * or a negative status, which the gather passes on. */
+typedef struct sacamd_transport {
+  void *self;
+  int rank, world;
+  int (*allgather_i64)(void *self, const long long *send, long long *recv, int count);
+  int (*group_begin)(void *self);
+  int (*send)(void *self, int peer, const void *buf, long long bytes);
+  int (*recv)(void *self, int peer, void *buf, long long bytes);
+  int (*group_end)(void *self);
+} sacamd_transport;
+int sacamd_gather_records_via(const sacamd_transport *t, int nrec, const int *frame_id, const uint8_t *recs,
+                              const long long *rec_off, int total_frames, uint8_t *out, long long cap, long long *out_off);
 
 /* ---- parity taps (tests) -------------------------------------------------------------------
  * Per-stage streams of one frame for one profile: p_lpc, p_lpc+p_lms (file-channel order),

@@ -36,6 +36,12 @@
 #include "file/sac.h"
 #include "opt/opt.h"
 #include "opt/ssc.h"
+#include "opt/de.h"
+#include "opt/cma.h"
+#include "common/math.h"
+#include <memory>
+#include <span>
+#include <tuple>
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -117,6 +123,182 @@ struct DriverDDS : public Opt {
     return run_mt(func, xstart);
   }
 };
+
+// RESTATED from opt/de.cpp:10-184 (needs <format>): OptDE's population loop around the genuine Opt base
+// (Random, gen_norm_samples, reflect) and the genuine DECfg (opt/de.h); evaluation is serial (eval_pop_pool's
+// result does not depend on the thread count: func is pure).
+struct DriverDE : public Opt {
+  OptDE::DECfg cfg;
+  DriverDE(const OptDE::DECfg &c, const box_const &pb) : Opt(pb), cfg(c) {}
+  double gen_CR(double mCR) { return std::clamp(rand.r_norm(mCR, 0.1), 0.01, 1.0); }
+  double gen_F(double mF) { return std::clamp(rand.r_cauchy(mF, 0.1), 0.01, 1.0); }
+  std::vector<int> select_k_unique_except(int n, int ie, int k) {
+    std::vector<int> r;
+    if (k >= n - 1) return r;
+    std::vector<int> e(n);
+    std::iota(std::begin(e), std::end(e), 0);
+    std::erase(e, ie);
+    for (int i = 0; i < k; i++) {
+      int idx = rand.ru_int(0, e.size() - 1);
+      int val = e[idx];
+      r.push_back(val);
+      std::erase(e, val);
+    }
+    return r;
+  }
+  vec1D mut_curbest(const vec1D &xbest, const vec1D &xb, const vec1D &x1, const vec1D &x2, double F) {
+    vec1D xm(ndim);
+    for (int i = 0; i < ndim; i++) {
+      double y = xb[i] + F * (xbest[i] - xb[i]) + F * (x1[i] - x2[i]);
+      xm[i] = reflect(y, pb[i].xmin, pb[i].xmax);
+    }
+    return xm;
+  }
+  vec1D mut_1bin(const vec1D &xb, const vec1D &x1, const vec1D &x2, double F) {
+    vec1D xm(ndim);
+    for (int i = 0; i < ndim; i++) {
+      double y = xb[i] + F * (x1[i] - x2[i]);
+      xm[i] = reflect(y, pb[i].xmin, pb[i].xmax);
+    }
+    return xm;
+  }
+  auto generate_candidate(const opt_points &pop, const vec1D &xbest, int iagent, double mCR, double mF) {
+    const double tCR = gen_CR(mCR);
+    const double tF = gen_F(mF);
+    const int R = rand.ru_int(0, ndim - 1);
+    auto gp = [&](int i) -> auto & { return pop[i].second; };
+    const int mutvals = cfg.mut_method == OptDE::RAND1BIN ? 3 : 2;     // OptDE::MutVals (opt/de.h:10-15)
+    auto v = select_k_unique_except(pop.size(), iagent, mutvals);
+    vec1D xm;
+    if (cfg.mut_method == OptDE::BEST1BIN) xm = mut_1bin(xbest, gp(v[0]), gp(v[1]), tF);
+    else if (cfg.mut_method == OptDE::RAND1BIN) xm = mut_1bin(gp(v[0]), gp(v[1]), gp(v[2]), tF);
+    else if (cfg.mut_method == OptDE::CUR1BEST) xm = mut_curbest(xbest, gp(iagent), gp(v[0]), gp(v[1]), tF);
+    else {
+      int np = std::min(cfg.npbest, static_cast<int>(pop.size()) - 1);
+      int xp = np > 0 ? rand.ru_int(0, np) : 0;
+      xm = mut_curbest(gp(xp), gp(iagent), gp(v[0]), gp(v[1]), tF);
+    }
+    vec1D xtrial(ndim);
+    const ppoint &xi = pop[iagent];
+    for (int i = 0; i < ndim; i++) {
+      if (rand.event(tCR) || (i == R)) xtrial[i] = xm[i];
+      else xtrial[i] = xi.second[i];
+    }
+    return std::tuple{xtrial, tCR, tF};
+  }
+  ppoint run(opt_func func, const vec1D &xstart) override {
+    std::size_t nfunc = 1;
+    ppoint xb{func(xstart), xstart};
+    opt_points pop(cfg.NP);
+    pop[0] = xb;
+    std::span<ppoint> pop_span(pop.begin() + 1, pop.end());
+    for (auto &x : pop_span) {
+      vec1D xt;
+      if (cfg.init_method == OptDE::INIT_UNIV) xt = gen_uniform_samples(xb.second, cfg.sigma_init);
+      else xt = gen_norm_samples(xb.second, cfg.sigma_init);
+      x.second = xt;
+    }
+    for (auto &x : pop_span) { x.first = func(x.second); nfunc++; }
+    for (const auto &x : pop_span)
+      if (x.first < xb.first) xb = x;
+    double mCR = cfg.CR, mF = cfg.F;
+    opt_points gen_pop;
+    std::vector<std::pair<double, double>> gen_mut;
+    while (nfunc < cfg.nfunc_max) {
+      if (cfg.mut_method == OptDE::CURPBEST)
+        std::sort(begin(pop), end(pop), [](const auto &a, const auto &b) { return a.first < b.first; });
+      const int num_agents = std::min(cfg.nfunc_max - nfunc, pop.size());
+      gen_mut.resize(num_agents);
+      gen_pop.resize(num_agents);
+      for (int iagent = 0; iagent < num_agents; iagent++) {
+        auto [xtrial, tCR, tF] = generate_candidate(pop, xb.second, iagent, mCR, mF);
+        gen_mut[iagent] = {tCR, tF};
+        gen_pop[iagent].second = xtrial;
+      }
+      for (auto &x : gen_pop) { x.first = func(x.second); nfunc++; }
+      std::vector<double> CR_succ, F_succ;
+      for (int iagent = 0; iagent < num_agents; iagent++)
+        if (gen_pop[iagent].first < pop[iagent].first) {
+          pop[iagent] = gen_pop[iagent];
+          CR_succ.push_back(gen_mut[iagent].first);
+          F_succ.push_back(gen_mut[iagent].second);
+          if (pop[iagent].first < xb.first) xb = pop[iagent];
+        }
+      if (nfunc >= cfg.nfunc_max) break;
+      mCR = (1.0 - cfg.c) * mCR + cfg.c * MathUtils::mean(CR_succ);
+      mF = (1.0 - cfg.c) * mF + cfg.c * MathUtils::meanL(F_succ);
+    }
+    return xb;
+  }
+};
+
+// RESTATED from opt/cma.cpp:6-92 (needs <format>): the (1+1)-CMA loop around the genuine slmath::Cholesky / mul /
+// mul_add / outer (common/math.h), SSC1 (opt/ssc.h), CMAParams (opt/cma.h) and Opt base.
+struct DriverCMA : public Opt {
+  OptCMA::CMACfg cfg;
+  OptCMA::CMAParams p;
+  slmath::Cholesky chol;
+  DriverCMA(const OptCMA::CMACfg &c, const box_const &pb) : Opt(pb), cfg(c), p(ndim), chol(ndim) {
+    p.sigma = cfg.sigma_init;
+    p.psucc = p.p_target_succ;
+  }
+  auto generate_candidate(const vec1D &x, double sigma) {
+    vec1D z(ndim);
+    for (auto &r : z) r = rand.r_norm();
+    vec1D az = slmath::mul(chol.G, z);
+    vec1D xgen(ndim);
+    for (int i = 0; i < ndim; i++) {
+      double scale = (pb[i].xmax - pb[i].xmin) * sigma;
+      double xnew = x[i] + scale * az[i];
+      xgen[i] = reflect(xnew, pb[i].xmin, pb[i].xmax);
+    }
+    return std::tuple{xgen, az};
+  }
+  void update_cov(vec2D &mcov, vec1D &pc, const vec1D &az) {
+    pc = slmath::mul_add(1.0 - p.cc, pc, std::sqrt(p.cc * (2.0 - p.cc)), az);
+    mcov = slmath::mul_add(1.0 - p.ccov, mcov, p.ccov, slmath::outer(pc, pc));
+  }
+  ppoint run(opt_func func, const vec1D &xstart) override {
+    vec1D pc(ndim);
+    vec2D mcov(ndim, vec1D(ndim));
+    for (int i = 0; i < ndim; i++) mcov[i][i] = 1.0;
+    SSC1 ssc(p.p_target_succ, p.cp, 1.0 / p.d);
+    int nfunc = 1;
+    ppoint xb{func(xstart), xstart};
+    while (nfunc < cfg.nfunc_max) {
+      chol.Factor(mcov, 0.1);
+      auto [xgen, az] = generate_candidate(xb.second, p.sigma);
+      double fn = func(xgen);
+      double lambda = (fn < xb.first) ? 1.0 : 0.0;
+      p.sigma = ssc.update(p.sigma, lambda);
+      if (fn < xb.first) {
+        xb.first = fn;
+        xb.second = xgen;
+        update_cov(mcov, pc, az);
+      }
+      nfunc++;
+    }
+    return xb;
+  }
+};
+
+// the searcher FrameCoder::Optimize would construct (libsac.cpp:408-415) with the settings cmdline.cpp:221-241 derives
+std::unique_ptr<Opt> make_searcher(int search, int maxnfunc, int num_threads, double sigma, const Opt::box_const &pb) {
+  if (search == 1) {
+    OptDE::DECfg c;
+    c.nfunc_max = maxnfunc; c.num_threads = std::max(num_threads, 1); c.sigma_init = sigma;
+    return std::make_unique<DriverDE>(c, pb);
+  }
+  if (search == 2) {
+    OptCMA::CMACfg c;
+    c.nfunc_max = maxnfunc; c.num_threads = std::max(num_threads, 1); c.sigma_init = sigma;
+    return std::make_unique<DriverCMA>(c, pb);
+  }
+  OptDDS::DDSCfg c;
+  c.nfunc_max = maxnfunc; c.num_threads = num_threads; c.sigma_init = sigma;
+  return std::make_unique<DriverDDS>(c, pb);
+}
+int g_search_method = 0;   // FrameCoder::SearchMethod for the next ref_encode_frame calls: 0 DDS, 1 DE, 2 CMA
 
 FrameCoder::tsac_cfg make_cfg(int optk, int sparse_pcm, int zero_mean) {
   FrameCoder::tsac_cfg cfg;
@@ -409,6 +591,28 @@ API double ref_dds_quadratic(int ndim, const double *xmin, const double *xmax,
   return ret.first;
 }
 
+// any searcher on the same analytic function: search 0 DDS, 1 DE, 2 CMA (settings as cmdline.cpp:221-241 derives them)
+API double ref_search_quadratic(int search, int ndim, const double *xmin, const double *xmax, const double *xstart, const double *center,
+                                int nfunc_max, int num_threads, double sigma, double *xbest, double *trace_cost, int *neval) {
+  Opt::box_const pb(ndim);
+  vec1D xs(ndim);
+  for (int i = 0; i < ndim; i++) { pb[i] = {xmin[i], xmax[i]}; xs[i] = xstart[i]; }
+  auto opt = make_searcher(search, nfunc_max, num_threads, sigma, pb);
+  int ne = 0;
+  auto f = [&](const vec1D &x) {
+    double s = 0;
+    for (int i = 0; i < ndim; i++) s += std::fabs(x[i] - center[i]) / (i + 1);   // no multiply-add: the same value with or without FMA contraction
+    if (trace_cost) trace_cost[ne] = s;
+    ne++;
+    return s;
+  };
+  auto ret = opt->run(f, xs);
+  for (int i = 0; i < ndim; i++) xbest[i] = ret.second[i];
+  if (neval) *neval = ne;
+  return ret.first;
+}
+API void ref_set_search_method(int search) { g_search_method = search; }
+
 // ---------------------------------------------------------------- whole-frame encode/decode
 struct ref_frame_cfg {
   int optimize;      // 0/1
@@ -493,7 +697,7 @@ API int ref_encode_frame(int nch, int framesize, int n, const int32_t *raw,
       for (int i = 0; i < ndim; i++) tmp_profile.coefs[lp[i]].vdef = x[i];
       fc.PredictFrame(tmp_profile, tmp_error, start_pos, samples_to_optimize, true);
       double c = fc.GetCost(CostFunc, tmp_error, samples_to_optimize);
-      if (neval < rc->maxnfunc) {
+      if (neval < rc->maxnfunc + 32) {   // + 32: DE evaluates its whole start-up population (30 points) even when maxnfunc is smaller
         if (trace_cost) trace_cost[neval] = c;
         if (trace_coefs)
           for (int i = 0; i < 58; i++) trace_coefs[(size_t)neval * 58 + i] = tmp_profile.coefs[i].vdef;
@@ -501,8 +705,8 @@ API int ref_encode_frame(int nch, int framesize, int n, const int32_t *raw,
       neval++;
       return c;
     };
-    DriverDDS dds(cfg.ocfg.dds_cfg, pb);
-    Opt::ppoint ret = dds.run(cost_func, xstart);
+    std::unique_ptr<Opt> searcher = make_searcher(g_search_method, rc->maxnfunc, rc->num_threads, rc->sigma, pb);
+    Opt::ppoint ret = searcher->run(cost_func, xstart);
     for (int i = 0; i < ndim; i++) profile.coefs[lp[i]].vdef = ret.second[i];
     delete CostFunc;
   }

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsac_amd.so")
 NUM_COEFS = 58
 COST_L1, COST_RMS, COST_ENTROPY, COST_GOLOMB, COST_BITPLANE = 0, 1, 2, 3, 4
+SEARCH_DDS, SEARCH_DE, SEARCH_CMA = 0, 1, 2
 
 ABI_SYMBOLS = [
     "sacamd_ctx_create", "sacamd_ctx_destroy", "sacamd_last_error", "sacamd_default_profile",
@@ -23,7 +24,8 @@ ABI_SYMBOLS = [
     "sacamd_predict_final", "sacamd_get_residuals", "sacamd_encode", "sacamd_get_encoded",
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
     "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
-    "sacamd_decode_frames",
+    "sacamd_decode_frames", "sacamd_comm_unique_id", "sacamd_comm_create", "sacamd_comm_destroy", "sacamd_comm_last_error",
+    "sacamd_gather_records", "sacamd_gather_records_via",
 ]
 
 
@@ -35,7 +37,7 @@ class Cfg(ctypes.Structure):
     """sacamd_cfg == FrameCoder::tsac_cfg + toptim_cfg flattened (libsac/libsac.h:19-44)."""
     _fields_ = [("optimize", c_int), ("sparse_pcm", c_int), ("zero_mean", c_int), ("reset", c_int),
                 ("fraction", c_double), ("maxnfunc", c_int), ("num_threads", c_int), ("sigma", c_double),
-                ("optk", c_int), ("optimize_cost", c_int)]
+                ("optk", c_int), ("optimize_cost", c_int), ("optimize_search", c_int)]
 
 
 _PRESETS = {  # cmdline.cpp:127-156
@@ -49,7 +51,7 @@ _PRESETS = {  # cmdline.cpp:127-156
 
 
 def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, fraction=None,
-             maxnfunc=None, cost=None, optk=4, sigma=None) -> Cfg:
+             maxnfunc=None, cost=None, optk=4, sigma=None, search=SEARCH_DDS) -> Cfg:
     """A preset of the reference's command line (cmdline.cpp:127-156) as a Cfg.  Note reset=1 (== --opt-reset) is the
     default HERE because the batch drivers run all frames in lock-step: with reset=0 (the reference's default, and what
     sacamd_default_cfg returns) a frame's search starts from the profile the caller passes in profiles_io, so chaining
@@ -57,13 +59,13 @@ def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, f
     o, f, e, s, c = _PRESETS[mode]
     return Cfg(o, sparse_pcm, zero_mean, reset, f if fraction is None else fraction,
                e if maxnfunc is None else maxnfunc, num_threads, s if sigma is None else sigma, optk,
-               c if cost is None else cost)
+               c if cost is None else cost, search)
 
 
 _lib = None
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def load_library():
@@ -121,6 +123,100 @@ def assign_frames(cost, world: int) -> np.ndarray:
     if rc != 0:
         raise SacAmdError(f"sacamd_assign_frames failed ({rc})")
     return owner
+
+
+# ---- multi-GPU record gather (include/sac_amd.h "multi-GPU record gather")
+COMM_ID_BYTES = 128
+_AG = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(c_longlong), POINTER(c_longlong), c_int)
+_GB = ctypes.CFUNCTYPE(c_int, c_void_p)
+_SR = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_longlong)
+
+
+class TransportC(ctypes.Structure):
+    """sacamd_transport"""
+    _fields_ = [("self", c_void_p), ("rank", c_int), ("world", c_int), ("allgather_i64", _AG), ("group_begin", _GB),
+                ("send", _SR), ("recv", _SR), ("group_end", _GB)]
+
+
+def _pack_records(frame_ids, recs):
+    ids = np.ascontiguousarray(frame_ids, np.int32)
+    off = np.zeros(len(recs) + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in recs])
+    blob = np.frombuffer(b"".join(recs), np.uint8).copy() if off[-1] else np.zeros(1, np.uint8)
+    return ids, off, blob
+
+
+def _default_cap(recs, total_frames):
+    # rank 0's receive buffer when the caller gives no capacity: frames of one job are of similar size
+    longest = max((len(r) for r in recs), default=0)
+    return total_frames * (2 * longest + (1 << 16)) if longest else max(64, total_frames) * (4 << 20)
+
+
+def _unpack_gathered(rc, out, out_off, total_frames, rank, err):
+    if rc != 0:
+        raise SacAmdError(f"record gather failed ({rc}): {err()}")
+    if rank != 0:
+        return None
+    return [out[out_off[f]: out_off[f + 1]].tobytes() for f in range(total_frames)]
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId (rank 0); hand the bytes to every rank's Comm()."""
+    lib = load_library()
+    buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+    rc = lib.sacamd_comm_unique_id(buf)
+    if rc != 0:
+        raise SacAmdError(f"sacamd_comm_unique_id failed ({rc})")
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of the record gather: one per process / GPU (ncclCommInitRank)."""
+
+    def __init__(self, device: int, rank: int, world: int, unique_id: bytes):
+        self.lib = load_library()
+        self.lib.sacamd_comm_last_error.restype = c_char_p
+        self.lib.sacamd_comm_last_error.argtypes = [c_void_p]
+        self.lib.sacamd_comm_destroy.argtypes = [c_void_p]
+        self.rank, self.world = rank, world
+        h = c_void_p()
+        idb = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        rc = self.lib.sacamd_comm_create(int(device), int(rank), int(world), idb, byref(h))
+        if rc != 0:
+            raise SacAmdError(f"sacamd_comm_create failed ({rc})")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sacamd_comm_destroy(self.h)
+            self.h = None
+
+    def gather_records(self, frame_ids, recs, total_frames: int, cap: int = None):
+        """Collective.  recs: this rank's frame records, frame_ids their global frame numbers.  Rank 0 returns the list of
+        all total_frames records in frame order (what WriteEncoded appends to the file), other ranks None."""
+        ids, off, blob = _pack_records(frame_ids, recs)
+        if self.rank == 0:
+            cap = int(cap) if cap is not None else _default_cap(recs, total_frames)
+            out = np.zeros(cap, np.uint8); out_off = np.zeros(total_frames + 1, np.int64)
+        else:
+            cap, out, out_off = 0, None, None
+        rc = self.lib.sacamd_gather_records(self.h, len(recs), _vp(ids), _vp(blob), _vp(off), int(total_frames), _vp(out),
+                                            c_longlong(cap), _vp(out_off))
+        return _unpack_gathered(rc, out, out_off, total_frames, self.rank, lambda: self.lib.sacamd_comm_last_error(self.h).decode())
+
+
+def gather_records_via(transport: TransportC, frame_ids, recs, total_frames: int, cap: int = None):
+    """The same gather over a caller-supplied transport (sacamd_gather_records_via)."""
+    lib = load_library()
+    ids, off, blob = _pack_records(frame_ids, recs)
+    if transport.rank == 0:
+        cap = int(cap) if cap is not None else _default_cap(recs, total_frames)
+        out = np.zeros(cap, np.uint8); out_off = np.zeros(total_frames + 1, np.int64)
+    else:
+        cap, out, out_off = 0, None, None
+    rc = lib.sacamd_gather_records_via(byref(transport), len(recs), _vp(ids), _vp(blob), _vp(off), int(total_frames), _vp(out),
+                                       c_longlong(cap), _vp(out_off))
+    return _unpack_gathered(rc, out, out_off, total_frames, transport.rank, lambda: "transport / argument error")
 
 
 class Context:

@@ -17,16 +17,10 @@ using Coef = sacamd::BoxCoef;
 
 namespace {
 
-struct FrameSearch {
-  std::mt19937 eng{0};                       // Opt::rand seeded 0 per optimiser (opt.cpp:5), one per frame (libsac.cpp:410)
-  std::vector<double> xb; double cb = 0.0;   // best point / cost
-  double sigma = 0.2;
-  int nfunc = 1;
-  int nsucc = 0, nfail = 0;                  // SSC0
-  double p_succ = 0.05;                      // SSC1(0.05,0.10,0.05)
-  std::vector<std::vector<double>> gen;      // candidates of the current generation
-  std::vector<double> gcost;
-
+// Opt::rand (common/rand.h) seeded 0 per optimiser instance (opt.cpp:5), one optimiser per frame (libsac.cpp:410),
+// and Opt::reflect; shared by the three searchers.
+struct SearchRng {
+  std::mt19937 eng{0};
   double r01() { return std::uniform_real_distribution<double>{0, 1}(eng); }
   // std::normal_distribution<double>{0,1} constructed per draw (rand.h:25-27) == one polar-method
   // round returning y*mult; x*x+y*y is a fused multiply-add in the reference build.
@@ -42,6 +36,17 @@ struct FrameSearch {
     if (x > hi) { x = hi - (x - hi); if (x < lo) x = hi; }
     return x;
   }
+};
+
+struct FrameSearch : SearchRng {
+  std::vector<double> xb; double cb = 0.0;   // best point / cost
+  double sigma = 0.2;
+  int nfunc = 1;
+  int nsucc = 0, nfail = 0;                  // SSC0
+  double p_succ = 0.05;                      // SSC1(0.05,0.10,0.05)
+  std::vector<std::vector<double>> gen;      // candidates of the current generation
+  std::vector<double> gcost;
+
   std::vector<double> candidate(const Coef *box, const std::vector<int> &lp, int nfunc_max) {   // dds.cpp:12-30
     const int ndim = (int)lp.size();
     std::vector<int> J;

@@ -25,8 +25,10 @@ namespace sacamd {
 class FrameCoder {
  public:
   enum SearchCost { L1, RMS, Entropy, Golomb, Bitplane };   // libsac.h:14
-  struct toptim_cfg {                                         // libsac.h:19-31 (DDS fields only)
+  enum SearchMethod { DDS, DE, CMA };                        // libsac.h:15
+  struct toptim_cfg {                                         // libsac.h:19-31 (dds_cfg / de_cfg / cma_cfg are derived from these, cmdline.cpp:221-241)
     int reset = 0; double fraction = 0; int maxnfunc = 0; int num_threads = 0; double sigma = 0.2; int optk = 4;
+    SearchMethod optimize_search = DDS;
     SearchCost optimize_cost = Entropy;
   };
   struct tsac_cfg {                                           // libsac.h:32-44
@@ -98,7 +100,7 @@ class FrameCoder {
     sacamd_cfg c; sacamd_default_cfg(&c);
     c.optimize = cfg.optimize; c.sparse_pcm = cfg.sparse_pcm; c.zero_mean = cfg.zero_mean; c.reset = cfg.ocfg.reset;
     c.fraction = cfg.ocfg.fraction; c.maxnfunc = cfg.ocfg.maxnfunc; c.num_threads = cfg.ocfg.num_threads; c.sigma = cfg.ocfg.sigma;
-    c.optk = cfg.ocfg.optk; c.optimize_cost = (int)cfg.ocfg.optimize_cost;
+    c.optk = cfg.ocfg.optk; c.optimize_cost = (int)cfg.ocfg.optimize_cost; c.optimize_search = (int)cfg.ocfg.optimize_search;
     return c;
   }
   void chk(int rc) { if (rc != 0) throw std::runtime_error(std::string("sac_amd: ") + sacamd_last_error(ctx_)); }

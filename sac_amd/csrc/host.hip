@@ -26,6 +26,7 @@
 #include "../../include/sac_amd.h"
 #include "coder.h"
 #include "dds_host.h"
+#include "search_host.h"
 #include "kernels.h"
 #include "params.h"
 #include "pred_tables.h"
@@ -559,12 +560,12 @@ void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start
 }  // namespace
 
 // ================================================================== context
-API int sacamd_abi_version(void) { return 2; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes
+API int sacamd_abi_version(void) { return 3; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*)
 
 API void sacamd_default_cfg(sacamd_cfg *cfg) {
   std::memset(cfg, 0, sizeof(*cfg));
   cfg->optimize = 0; cfg->sparse_pcm = 1; cfg->zero_mean = 1; cfg->reset = 0; cfg->fraction = 0; cfg->maxnfunc = 0;
-  cfg->num_threads = 0; cfg->sigma = 0.2; cfg->optk = 4; cfg->optimize_cost = SACAMD_COST_ENTROPY;
+  cfg->num_threads = 0; cfg->sigma = 0.2; cfg->optk = 4; cfg->optimize_cost = SACAMD_COST_ENTROPY; cfg->optimize_search = SACAMD_SEARCH_DDS;
 }
 
 API int sacamd_default_profile(float *vmin, float *vmax, float *vdef) {
@@ -1072,3 +1073,4 @@ API int sacamd_kernel_times(sacamd_ctx *c, double *out16, int reset) {
 
 #include "host_encode.inc"
 #include "host_decode.inc"
+#include "host_gather.inc"

@@ -9,6 +9,8 @@
 // (sacamd_plan_subframes), every frame of every input file staged as ONE batch per max-frames
 // (frames are independent: --opt-reset semantics), records written behind the SAC2 header + MD5.
 // With several inputs the last argument is a directory.  Host code only; no CPU compute path.
+#include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +50,18 @@ int main(int argc, char **argv) {
       else if (a == "--extrahigh") preset(1, 0.2, 600, 0.25, SACAMD_COST_ENTROPY);
       else if (a == "--best") preset(1, 0.5, 1000, 0.25, SACAMD_COST_BITPLANE);
       else if (a == "--insane") preset(1, 0.5, 1500, 0.25, SACAMD_COST_BITPLANE);
-      else if (a.rfind("--opt-cfg=dds,", 0) == 0) cfg.num_threads = std::atoi(a.c_str() + 14);
+      else if (a.rfind("--opt-cfg=", 0) == 0) {                                           // cmdline.cpp:195-207: method[,threads[,sigma]]
+        std::string v = a.substr(10), m = v.substr(0, v.find(','));
+        for (auto &ch : m) ch = (char)std::toupper((unsigned char)ch);
+        if (m == "DDS") cfg.optimize_search = SACAMD_SEARCH_DDS; else if (m == "DE") cfg.optimize_search = SACAMD_SEARCH_DE;
+        else if (m == "CMA") cfg.optimize_search = SACAMD_SEARCH_CMA; else std::cerr << "  warning: invalid opt='" << m << "'\n";
+        size_t c1 = v.find(',');
+        if (c1 != std::string::npos) {
+          cfg.num_threads = std::min(std::max(std::atoi(v.c_str() + c1 + 1), 0), 256);
+          size_t c2 = v.find(',', c1 + 1);
+          if (c2 != std::string::npos) cfg.sigma = std::min(std::max(std::atof(v.c_str() + c2 + 1), 0.0), 1.0);
+        }
+      }
       else if (a.rfind("--framelen=", 0) == 0) framelen = std::atoi(a.c_str() + 11);
       else if (a == "--adapt-block=no" || a == "--adapt-block=0") adapt_block = 0;
       else if (a.rfind("--max-frames=", 0) == 0) max_frames = std::atoi(a.c_str() + 13);

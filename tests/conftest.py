@@ -47,6 +47,14 @@ def golden_r2():
 
 
 @pytest.fixture(scope="session")
+def golden_r4():
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", "ref_golden_r4.npz")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def golden_r3():
     import numpy as np
 

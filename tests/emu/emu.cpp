@@ -189,6 +189,47 @@ API double emu_dds_quadratic(int ndim, const double *xmin, const double *xmax, c
   return fs.cb;
 }
 
+// the DE / CMA searchers (product code, search_host.h) on the same test function: search 1 = DE, 2 = CMA
+#include "../../sac_amd/csrc/search_host.h"
+template <class S>
+static double run_searcher_quadratic(S &sr, int ndim, const double *xmin, const double *xmax, const double *xstart, const double *center,
+                                     int nfunc_max, double sigma, double *xbest, double *trace_cost, int *neval) {
+  SearchBox box; box.lo.assign(xmin, xmin + ndim); box.hi.assign(xmax, xmax + ndim);
+  int ne = 0;
+  auto f = [&](const std::vector<double> &x) {
+    double s = 0;
+    for (int i = 0; i < ndim; i++) s += std::fabs(x[i] - center[i]) / (i + 1);   // no multiply-add: the same value with or without FMA contraction
+    if (trace_cost) trace_cost[ne] = s;
+    ne++;
+    return s;
+  };
+  std::vector<double> x0(xstart, xstart + ndim);
+  sr.start(&box, x0, f(x0), nfunc_max, sigma);
+  for (;;) {
+    const auto &gen = sr.propose();
+    if (gen.empty()) break;
+    std::vector<double> gc(gen.size());
+    for (size_t i = 0; i < gen.size(); i++) gc[i] = f(gen[i]);
+    sr.accept(gc.data());
+  }
+  if (neval) *neval = ne;
+  return 0.0;
+}
+API double emu_search_quadratic(int search, int ndim, const double *xmin, const double *xmax, const double *xstart, const double *center,
+                                int nfunc_max, int num_threads, double sigma, double *xbest, double *trace_cost, int *neval) {
+  (void)num_threads;
+  if (search == 1) {
+    FrameSearchDE de;
+    run_searcher_quadratic(de, ndim, xmin, xmax, xstart, center, nfunc_max, sigma, xbest, trace_cost, neval);
+    for (int i = 0; i < ndim; i++) xbest[i] = de.best.x[i];
+    return de.best.cost;
+  }
+  FrameSearchCMA cma;
+  run_searcher_quadratic(cma, ndim, xmin, xmax, xstart, center, nfunc_max, sigma, xbest, trace_cost, neval);
+  for (int i = 0; i < ndim; i++) xbest[i] = cma.xbest[i];
+  return cma.cbest;
+}
+
 // ---------------------------------------------------------------- libm port vs the host libm
 #include <random>
 API long emu_libm_mismatches(long n, int seed) {

@@ -90,6 +90,29 @@ def main_r3():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def main_r4():
+    """tests/golden/ref_golden_r4.npz (round 3): the DE and CMA searchers (--opt-cfg=de / cma) -- traces on an analytic
+    function and frame records, from oracle/_ref (DriverDE / DriverCMA around the genuine Opt, Cholesky, SSC1)."""
+    from golden_cases import search_cases, search_quadratic_cases, search_quadratic_inputs
+    R = Checker("ref")
+    out = {}
+    for name, (search, ndim, nmax, sigma, seed) in search_quadratic_cases().items():
+        lo, hi, xs, cen = search_quadratic_inputs(ndim, seed)
+        best, xb, tc = R.search_quadratic(search, lo, hi, xs, cen, nmax, sigma)
+        out[f"quad/{name}/xbest"] = xb; out[f"quad/{name}/trace"] = tc
+    for name, (raw, cfg, search) in search_cases().items():
+        r = R.encode_frame(raw, cfg, FRAMESIZE, trace=True, search=search)
+        out[f"search/{name}/raw"] = raw.astype(np.int16)
+        out[f"search/{name}/record"] = np.frombuffer(r["record"], np.uint8)
+        out[f"search/{name}/profile"] = r["profile"]
+        out[f"search/{name}/trace_cost"] = r["trace_cost"]
+        out[f"search/{name}/trace_coefs"] = r["trace_coefs"]
+        print(name, len(r["record"]), "bytes")
+    path = os.path.join(HERE, "ref_golden_r4.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     R = Checker("ref")
     out = {}
@@ -173,5 +196,7 @@ if __name__ == "__main__":
         main_r2()
     elif "--r3" in sys.argv:
         main_r3()
+    elif "--r4" in sys.argv:
+        main_r4()
     else:
         main()

@@ -86,6 +86,32 @@ def chain_cases():
     return c
 
 
+def search_cases():
+    """name -> (raw PCM, FrameCfg, search method): --opt-cfg=de / cma (FrameCoder::SearchMethod 1 / 2) on small frames.
+    DE evaluates 1 + 29 start-up points, then generations of min(30, E - evaluated) trial vectors: E = 75 ends on a
+    15-vector generation, E = 31 on a single one; E = 20 < 30 still evaluates the whole start-up population."""
+    c = {}
+    c["s16_de_e75"] = (synth_pcm(4000, 2, 81, RATE), frame_cfg("high", maxnfunc=75), 1)
+    c["m16_de_e31"] = (synth_pcm(3000, 1, 82, RATE), frame_cfg("high", maxnfunc=31, sigma=0.15), 1)
+    c["m16_de_e20"] = (synth_pcm(2500, 1, 83, RATE), frame_cfg("high", maxnfunc=20), 1)
+    c["s16_cma_e40"] = (synth_pcm(4000, 2, 84, RATE), frame_cfg("high", maxnfunc=40), 2)
+    c["m16_cma_e25"] = (synth_pcm(3000, 1, 85, RATE), frame_cfg("high", maxnfunc=25, sigma=0.25), 2)
+    return c
+
+
+def search_quadratic_cases():
+    """name -> (search, ndim, nfunc_max, sigma, seed) for the searchers on the analytic test function"""
+    return {"de_56_100": (1, 56, 100, 0.2, 1), "de_13_500": (1, 13, 500, 0.2, 4), "de_3_31": (1, 3, 31, 0.2, 6), "de_56_20": (1, 56, 20, 0.2, 7),
+            "cma_56_100": (2, 56, 100, 0.2, 1), "cma_13_500": (2, 13, 500, 0.2, 4), "cma_7_40": (2, 7, 40, 0.15, 3)}
+
+
+def search_quadratic_inputs(ndim, seed):
+    rng = np.random.default_rng(seed)
+    xmin = -rng.uniform(0.5, 3, ndim); xmax = rng.uniform(0.5, 100, ndim)
+    xs = xmin + (xmax - xmin) * rng.uniform(0.2, 0.8, ndim); cen = xmin + (xmax - xmin) * rng.uniform(0, 1, ndim)
+    return xmin, xmax, xs, cen
+
+
 FULL_RATE = 44100
 FULL_FRAMESIZE = 20 * FULL_RATE
 

@@ -229,21 +229,40 @@ class Checker:
                                        nfunc_max, num_threads, c_double(sigma), _vp(xb), _vp(tc))
         return best, xb, tc
 
+    def search_quadratic(self, search, xmin, xmax, xstart, center, nfunc_max, sigma, num_threads=1):
+        """DriverDDS / DriverDE / DriverCMA (search 0 / 1 / 2; oracle/ref_driver.cpp) on f(x) = sum |x_i - c_i| / (i+1);
+        genuine-reference checker only.  -> (best cost, best point, cost of every evaluation)"""
+        assert self.prefix == "ref"
+        xmin = np.ascontiguousarray(xmin, np.float64); xmax = np.ascontiguousarray(xmax, np.float64)
+        xstart = np.ascontiguousarray(xstart, np.float64); center = np.ascontiguousarray(center, np.float64)
+        xb = np.zeros(xmin.size); tc = np.zeros(nfunc_max + 64); ne = ctypes.c_int(0)
+        fn = self.lib.ref_search_quadratic; fn.restype = c_double
+        best = fn(int(search), xmin.size, _vp(xmin), _vp(xmax), _vp(xstart), _vp(center), int(nfunc_max), int(num_threads),
+                  c_double(sigma), _vp(xb), _vp(tc), byref(ne))
+        return best, xb, tc[: ne.value].copy()
+
     # ---- whole frame
-    def encode_frame(self, raw, cfg: FrameCfg, framesize, profile=None, trace=False):
+    def encode_frame(self, raw, cfg: FrameCfg, framesize, profile=None, trace=False, search=0):
+        """search: FrameCoder::SearchMethod 0 DDS, 1 DE, 2 CMA (the two latter with the genuine-reference checker only)."""
+        if search:
+            assert self.prefix == "ref", "DE / CMA searches exist in oracle/_ref only"
+        if self.prefix == "ref":
+            self.lib.ref_set_search_method(int(search))
         raw = np.ascontiguousarray(raw, np.int32)
         nch, n = raw.shape
         prof = self.profile()[:, 2].copy() if profile is None else np.ascontiguousarray(profile, np.float32).copy()
         out = np.zeros(n * nch * 4 + 65536 * 2 + 4096, np.uint8)
         info = np.zeros(6, np.int32)
-        tc = np.zeros(max(cfg.maxnfunc, 1)) if trace else None
-        tg = np.zeros((max(cfg.maxnfunc, 1), 58), np.float32) if trace else None
+        ntr = max(cfg.maxnfunc, 1) + 32          # ref_driver: up to maxnfunc + 32 evaluations are traced (DE start-up population)
+        tc = np.full(ntr, np.nan) if trace else None
+        tg = np.zeros((ntr, 58), np.float32) if trace else None
         m = self.f("encode_frame")(nch, framesize, n, _vp(raw), byref(cfg), _vp(prof), _vp(out), out.size,
                                    _vp(tc), _vp(tg), _vp(info))
         assert m > 0, m
         res = {"record": out[:m].tobytes(), "profile": prof, "info": info.reshape(2, 3)[:nch]}
         if trace:
-            res["trace_cost"] = tc; res["trace_coefs"] = tg
+            nev = int(np.count_nonzero(~np.isnan(tc))) if search else max(cfg.maxnfunc, 1)
+            res["trace_cost"] = tc[:nev]; res["trace_coefs"] = tg[:nev]
         return res
 
     def decode_frame(self, rec: bytes, nch, framesize):

@@ -38,7 +38,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     import sac_amd.api as api
     assert sorted(api.ABI_SYMBOLS) == declared
-    assert lib.sacamd_abi_version() == 2
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 3
     # without a GPU the context constructor must fail loudly (no CPU fallback)
     import torch
     if not torch.cuda.is_available():
@@ -121,6 +121,23 @@ def test_host_dds_driver_matches_reference_search(emu, golden):
         assert np.allclose(tc, golden[f"dds/q{nt}/trace"], rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("name", list(__import__("golden_cases").search_quadratic_cases().keys()))
+def test_host_de_cma_searchers_match_reference(emu, golden_r4, name):
+    """search_host.h (FrameSearchDE / FrameSearchCMA, product host code) vs opt/de.cpp / opt/cma.cpp as oracle/_ref runs
+    them: every evaluated point's cost and the best point bit-identical (the test function has no multiply-add, so it
+    is the same with and without FMA contraction)."""
+    from golden_cases import search_quadratic_cases, search_quadratic_inputs
+    search, ndim, nmax, sigma, seed = search_quadratic_cases()[name]
+    lo, hi, xs, cen = search_quadratic_inputs(ndim, seed)
+    xb = np.zeros(ndim); tc = np.zeros(nmax + 64); ne = ctypes.c_int(0)
+    emu.emu_search_quadratic.restype = ctypes.c_double
+    emu.emu_search_quadratic(search, ndim, _vp(lo), _vp(hi), _vp(xs), _vp(cen), nmax, 1, ctypes.c_double(sigma), _vp(xb), _vp(tc), ctypes.byref(ne))
+    want = golden_r4[f"quad/{name}/trace"]
+    assert ne.value == len(want)
+    assert np.array_equal(tc[: ne.value], want)
+    assert np.array_equal(xb, golden_r4[f"quad/{name}/xbest"])
+
+
 def test_device_libm_port_is_bit_exact_with_host_libm(emu):
     assert emu.emu_libm_mismatches(2_000_000, 3) == 0
 
@@ -154,16 +171,43 @@ if rank == 0:
     order = [f for r in range(world) for f in range(len(cost)) if ow[f] == r]
     got = dict(zip(order, out))
     assert [got[f] for f in range(len(cost))] == [bytes([f]) * (3 + 2 * f) for f in range(len(cost))]
-    print("GATHER_OK")
 else:
     assert out is None
+# the library's own gather (sacamd_gather_records_via == the gather_core the RCCL communicator drives) over a gloo transport:
+# cost-based ownership, ragged counts, records arrive on rank 0 in FRAME order; an empty record and an empty rank included
+sys.path.insert(0, {tests!r})
+from gloo_transport import make_transport
+tr = make_transport(rank, world)
+recs = [bytes([f]) * (3 + 2 * f) if f != 7 else b"" for f in mine]
+out = api.gather_records_via(tr, mine, recs, len(cost))
+if rank == 0:
+    assert out == [bytes([f]) * (3 + 2 * f) if f != 7 else b"" for f in range(len(cost))], out
+else:
+    assert out is None
+ids = list(range(5)) if rank == 1 else []                     # rank 0 owns nothing
+out = api.gather_records_via(tr, ids, [bytes([9 - f]) * (1 + f) for f in ids], 5)
+assert (out == [bytes([9 - f]) * (1 + f) for f in range(5)]) if rank == 0 else out is None
+# ids that are not a partition (frame 2 on both ranks): every rank gets the same error, nobody hangs
+try:
+    api.gather_records_via(tr, [2, rank], [b"x", b"y"], 3)
+    raise AssertionError("duplicate frame id accepted")
+except api.SacAmdError:
+    pass
+# receive buffer too small on rank 0: rank 0 reports it after serving the peers
+try:
+    r = api.gather_records_via(tr, [rank], [b"z" * 100], 2, cap=150)
+    assert rank != 0 and r is None
+except api.SacAmdError:
+    assert rank == 0
+if rank == 0:
+    print("GATHER_OK")
 dist.barrier(); dist.destroy_process_group()
 """
 
 
 def test_record_gather_two_ranks_gloo(tmp_path):
     script = tmp_path / "w.py"
-    script.write_text(GLOO_WORKER.format(root=ROOT))
+    script.write_text(GLOO_WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests")))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29577", str(script)],

@@ -6,8 +6,8 @@ bit-exact; fp64 intermediates within the tolerance written next to each assertio
 import numpy as np
 import pytest
 
-from golden_cases import (FRAMESIZE, FULL_FRAMESIZE, RATE, chain_cases, frame_cases, fullsize_cases, rand_profile, trace_cases,
-                          trace_cases_r2)
+from golden_cases import (FRAMESIZE, FULL_FRAMESIZE, RATE, chain_cases, frame_cases, fullsize_cases, rand_profile, search_cases,
+                          trace_cases, trace_cases_r2)
 from oracle_api import center_frame, frame_cfg, ref_available
 from sac_amd.synth import synth_pcm
 
@@ -23,12 +23,12 @@ def api():
 
 def gpu_cfg(api, cfg):
     return api.Cfg(cfg.optimize, cfg.sparse_pcm, cfg.zero_mean, cfg.reset, cfg.fraction, cfg.maxnfunc,
-                   cfg.num_threads, cfg.sigma, cfg.optk, cfg.cost)
+                   cfg.num_threads, cfg.sigma, cfg.optk, cfg.cost, 0)
 
 
 def test_library_is_the_hip_one(api):
     lib = api.load_library()
-    assert lib.sacamd_abi_version() == 2
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 3
     ctx = api.Context(2, 1000, 1)   # fails loudly without a gfx950 device
     ctx.close()
     assert np.array_equal(api.default_profile(), np.load(__import__("os").path.join(
@@ -604,3 +604,36 @@ def test_gpu_decoder_full_size_frame(api, orc):
     pcm, _ = ctx.decode_frames(recs, FULL_FRAMESIZE)
     ctx.close()
     assert np.array_equal(pcm[0], raw)
+
+
+def test_rccl_record_gather_single_rank(api):
+    """The library's RCCL communicator on the one GPU of this box (world 1): ncclCommInitRank, the two ncclAllGather
+    rounds of the gather and the frame-order scatter run for real; the grouped ncclSend/ncclRecv leg needs >= 2 GPUs and is
+    covered by the two-process gloo transport test on the CPU (same gather_core)."""
+    comm = api.Comm(0, 0, 1, api.comm_unique_id())
+    recs = [bytes([f]) * (5 + 7 * f) for f in (3, 0, 2, 1)]
+    out = comm.gather_records([3, 0, 2, 1], recs, 4)
+    assert out == [bytes([f]) * (5 + 7 * f) for f in range(4)]
+    with pytest.raises(api.SacAmdError):
+        comm.gather_records([0, 0], [b"a", b"b"], 2)
+    comm.close()
+
+
+@pytest.mark.parametrize("name", list(search_cases().keys()))
+def test_de_and_cma_searches_write_the_reference_records(api, golden_r4, name):
+    """--opt-cfg=de / cma (OptDE, OptCMA behind FrameCoder::Optimize): same chosen profile and byte-identical frame record
+    as oracle/_ref; the costs of the evaluated candidates agree with the reference's trace (search evaluations sum the
+    NLMS dots in free order: 1e-9 relative, as for DDS)."""
+    raw, cfg, search = search_cases()[name]
+    assert np.array_equal(raw, golden_r4[f"search/{name}/raw"].astype(np.int32))
+    ctx = api.Context(raw.shape[0], FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    g = gpu_cfg(api, cfg); g.optimize_search = search
+    recs, prof = ctx.encode_frames(g)
+    assert np.array_equal(prof[0], golden_r4[f"search/{name}/profile"])
+    assert recs[0] == golden_r4[f"search/{name}/record"].tobytes()
+    tcoefs = golden_r4[f"search/{name}/trace_coefs"]; tcost = golden_r4[f"search/{name}/trace_cost"]
+    ctx.upload_i32([raw], FRAMESIZE); ctx.analyse(g)
+    costs = ctx.evaluate(g, np.zeros(len(tcost), np.int32), tcoefs)
+    assert np.allclose(costs, tcost, rtol=1e-9, atol=0)
+    ctx.close()
