@@ -2,11 +2,13 @@
 
     python -m sac_amd.cli encode in.wav out.sac [--mode high] [--dds-n 8] [--framelen 20] [--no-adapt-block]
     python -m sac_amd.cli list file.sac
+    python -m sac_amd.cli decode file.sac out.wav      (GPU decoder: sacamd_decode_frames over all frame records at once)
 
 The encode side of the reference's command line (cmdline.cpp): presets --normal .. --insane,
 --opt-cfg=dds,N (here --dds-n), --framelen, --adapt-block.  Frames are always independent
-(--opt-reset), which is what makes them batchable.  Decoding is done by the reference decoder:
-the files are byte-compatible.
+(--opt-reset), which is what makes them batchable.  `decode` is the reference's --decode (cmdline.cpp:295-358,
+Codec::DecodeFile libsac.cpp:857-883) with all frames of the file decoded as one GPU batch; the files are
+byte-compatible with the reference's in both directions.
 """
 import argparse
 import sys
@@ -26,7 +28,24 @@ def main(argv=None):
     e.add_argument("--max-frames", type=int, default=256, help="frames per GPU batch")
     ls = sub.add_parser("list")
     ls.add_argument("sac")
+    d = sub.add_parser("decode")
+    d.add_argument("sac"); d.add_argument("wav")
     a = ap.parse_args(argv)
+    if a.cmd == "decode":
+        import hashlib
+        hdr, md5, chunks, recs = container.read_sac(a.sac)
+        nch, rate, bits, nsamp, framelen = hdr["numchannels"], hdr["samplerate"], hdr["bitspersample"], hdr["numsamples"], hdr["max_framelen"]
+        data = b""
+        if recs:
+            ctx = api.Context(nch, framelen * rate, min(len(recs), 256))
+            for b0 in range(0, len(recs), 256):
+                pcm, _ = ctx.decode_frames(recs[b0: b0 + 256], framelen * rate)
+                data += b"".join(container.sample_bytes(p, bits) for p in pcm)
+            ctx.close()
+        ok = hashlib.md5(data).digest() == md5
+        open(a.wav, "wb").write(container.rebuild_wav(chunks, data))
+        print(f"{a.sac}: {len(recs)} frames, {len(data)} sample bytes -> {a.wav}; Audio MD5: {'ok' if ok else 'Error'}")
+        return 0 if ok else 1
     if a.cmd == "list":
         hdr, md5, chunks, recs = container.read_sac(a.sac)
         print(hdr, "md5", md5.hex(), "frames", len(recs), "chunks", [(hex(c), s) for c, s, _ in chunks])

@@ -124,6 +124,18 @@ def pcm_from_wav(w: WavInfo) -> np.ndarray:
     return np.ascontiguousarray(a.reshape(-1, w.numchannels).T)
 
 
+def sample_bytes(pcm: np.ndarray, bits: int) -> bytes:
+    """Wav::WriteSamples packing (file/wav.cpp:124-160): int32 [nch, n] -> interleaved little-endian sample bytes."""
+    pcm = np.asarray(pcm)
+    csize = (bits + 7) // 8
+    if csize == 1:
+        return ((pcm.T + 128) & 0xFF).astype(np.uint8).tobytes()
+    if csize == 2:
+        return pcm.T.astype("<i2").tobytes()
+    raw = pcm.T.astype("<i4").tobytes()
+    return np.frombuffer(raw, np.uint8).reshape(-1, 4)[:, :csize].tobytes()
+
+
 def wav_bytes_from_pcm(pcm: np.ndarray, rate: int, bits: int = 16, extra_chunks=()) -> bytes:
     """A plain PCM WAV (tests / synthetic inputs)."""
     pcm = np.asarray(pcm)

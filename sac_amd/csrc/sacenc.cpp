@@ -3,6 +3,9 @@
 //   sacenc [--normal|--high|--veryhigh|--extrahigh|--best|--insane] [--opt-cfg=dds,N] [--framelen=S]
 //          [--adapt-block=no] [--max-frames=N] in.wav [more.wav ...] out.sac|outdir
 //   sacenc --list|--listfull file.sac       header, ratio, MD5 (and every frame record) as the reference's --list / --listfull
+//   sacenc --decode file.sac out.wav        .sac -> WAV on the GPU (cmdline.cpp:295-358, Codec::DecodeFile libsac.cpp:857-883):
+//                                           all frame records of the file decoded as one batch (sacamd_decode_frames),
+//                                           MD5 of the sample bytes checked against the header's
 //
 // The encode side of the reference's command line (/root/reference/src/cmdline.cpp:127-235) and of
 // Codec::EncodeFile (libsac/libsac.cpp:782-855): reads of framelen seconds, adaptive sub-frame split
@@ -39,6 +42,7 @@ int main(int argc, char **argv) {
     cfg.reset = 1;
     int framelen = 20, adapt_block = 1, max_frames = 256;
     int list_mode = 0;             // 1: --list, 2: --listfull (host only)
+    bool decode_mode = false;      // --decode
     bool header_only = false;      // --header-only: write header + MD5 of each input and stop (no device needed; tests)
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
@@ -68,6 +72,7 @@ int main(int argc, char **argv) {
       else if (a == "--header-only") header_only = true;
       else if (a == "--list") list_mode = 1;
       else if (a == "--listfull") list_mode = 2;
+      else if (a == "--decode") decode_mode = true;
       else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
       else pos.push_back(a);
     }
@@ -97,6 +102,49 @@ int main(int argc, char **argv) {
         if (!ok) { std::printf("warning: truncated frame record\n"); return 1; }
       }
       return 0;
+    }
+    if (decode_mode) {
+      if (pos.size() != 2) { std::cerr << "usage: sacenc --decode file.sac out.wav\n"; return 2; }
+      const std::vector<uint8_t> raw = slurp(pos[0]);
+      SacHeader h;
+      if (!read_sac_header(raw, h)) { std::cout << "warning: input is not a valid .sac file\n"; return 1; }
+      std::vector<WavChunk> chunks;
+      if (!unpack_metadata(raw.data() + 22, (size_t)h.metadatasize, chunks)) std::cerr << "  warning: unpackmetadata mismatch\n";
+      std::vector<SacFrameInfo> fr; long long chdr = 0, bhdr = 0;
+      if (!scan_sac_frames(raw, h, fr, &chdr, &bhdr)) throw std::runtime_error("truncated .sac file");
+      // record offsets (frame f = [off[f], off[f+1]) behind the header)
+      std::vector<long long> off(1, 0);
+      for (auto &f : fr) { long long len = 4 + 58 * 4; for (int c = 0; c < h.numchannels && c < 2; c++) len += 18 + f.ch[c].blocksize; off.push_back(off.back() + len); }
+      const int maxfs = h.samplerate * h.max_framelen, nf = (int)fr.size();
+      int bps_bytes = (h.bitspersample + 7) / 8;
+      for (auto &c : chunks) if (c.id == kIdFmt && c.payload.size() >= 14 && h.numchannels > 0) bps_bytes = rd16(&c.payload[12]) / h.numchannels;   // blockalign / channels
+      std::vector<uint8_t> data;
+      data.reserve((size_t)h.numsamples * h.numchannels * bps_bytes);
+      if (nf > 0) {
+        sacamd_ctx *ctx = nullptr;
+        const int batch = std::min(nf, max_frames);
+        if (sacamd_ctx_create(0, h.numchannels, maxfs, batch, &ctx) != 0) throw std::runtime_error("no usable gfx950 device (sacamd_ctx_create failed)");
+        std::vector<int32_t> pcm((size_t)batch * h.numchannels * maxfs);
+        std::vector<int> ns(batch);
+        for (int b0 = 0; b0 < nf; b0 += batch) {
+          const int nb = std::min(batch, nf - b0);
+          std::vector<long long> o(nb + 1);
+          for (int i = 0; i <= nb; i++) o[i] = off[b0 + i] - off[b0];
+          if (sacamd_decode_frames(ctx, nb, maxfs, raw.data() + h.frames_at + off[b0], o.data(), pcm.data(), (long long)h.numchannels * maxfs, maxfs, ns.data(), nullptr) != 0)
+            throw std::runtime_error(std::string("sac_amd: ") + sacamd_last_error(ctx));
+          for (int i = 0; i < nb; i++) pack_samples(&pcm[(size_t)i * h.numchannels * maxfs], maxfs, h.numchannels, ns[i], bps_bytes, data);
+        }
+        sacamd_ctx_destroy(ctx);
+      }
+      Md5 md; md.update(data.data(), data.size());
+      uint8_t dig[16]; md.finish(dig);
+      const std::vector<uint8_t> wav = rebuild_wav(chunks, data);
+      std::ofstream o(pos[1], std::ios::binary);
+      if (!o) { std::cout << "could not create\n"; return 1; }
+      o.write((const char *)wav.data(), (std::streamsize)wav.size());
+      const bool md5ok = std::memcmp(dig, h.md5, 16) == 0;
+      std::printf("%s: %d frames, %zu sample bytes -> %s\n  Audio MD5: %s\n", pos[0].c_str(), nf, data.size(), pos[1].c_str(), md5ok ? "ok" : "Error");
+      return md5ok ? 0 : 1;
     }
     if (pos.size() < 2 || framelen < 1 || framelen > 255 || max_frames < 1) { std::cerr << "usage: sacenc [options] in.wav [more.wav ...] out.sac|outdir\n"; return 2; }
     const std::string outarg = pos.back(); pos.pop_back();

@@ -168,6 +168,46 @@ inline bool read_sac_header(const std::vector<uint8_t> &raw, SacHeader &h) {
   h.frames_at = p + 16;
   return true;
 }
+// Chunks::UnpackMetaData (file/wav.cpp) inverse of pack_metadata: RIFF keeps its 4-byte form type, data has no payload,
+// every other chunk its word-aligned payload
+inline bool unpack_metadata(const uint8_t *m, size_t n, std::vector<WavChunk> &out) {
+  size_t p = 0;
+  while (p + 8 <= n) {
+    const uint32_t id = rd32(m + p), sz = rd32(m + p + 4);
+    p += 8;
+    const size_t len = id == kIdRiff ? 4 : (id == kIdData ? 0 : word_align(sz));
+    if (p + len > n) return false;
+    out.push_back({id, sz, std::vector<uint8_t>(m + p, m + p + len)});
+    p += len;
+  }
+  return p == n;
+}
+// Wav::WriteSamples (file/wav.cpp:124-160): planar int32 [ch][n] -> interleaved little-endian sample bytes
+inline void pack_samples(const int32_t *pcm, long long ch_stride, int nch, int n, int bytes_per_sample, std::vector<uint8_t> &out) {
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < nch; k++) {
+      const int32_t v = pcm[(size_t)k * ch_stride + i];
+      if (bytes_per_sample == 1) out.push_back((uint8_t)((v + 128) & 0xff));
+      else for (int b = 0; b < bytes_per_sample; b++) out.push_back((uint8_t)((uint32_t)v >> (8 * b)));
+    }
+}
+// the WAV file Codec::DecodeFile writes (libsac.cpp:857-883): chunks up to and including the data header, the samples,
+// a pad byte after an odd-sized data chunk, then the remaining chunks (Wav::WriteHeader, wav.cpp:265-281)
+inline std::vector<uint8_t> rebuild_wav(const std::vector<WavChunk> &chunks, const std::vector<uint8_t> &data) {
+  std::vector<uint8_t> o;
+  size_t i = 0;
+  while (i < chunks.size()) {
+    const WavChunk &c = chunks[i++];
+    wr32(o, c.id); wr32(o, c.size);
+    if (c.id == kIdData) break;
+    o.insert(o.end(), c.payload.begin(), c.payload.end());
+  }
+  o.insert(o.end(), data.begin(), data.end());
+  if (data.size() & 1) o.push_back(0);
+  for (; i < chunks.size(); i++) { wr32(o, chunks[i].id); wr32(o, chunks[i].size); o.insert(o.end(), chunks[i].payload.begin(), chunks[i].payload.end()); }
+  return o;
+}
+
 struct SacFrameInfo { int numsamples; struct Ch { int blocksize, mean, minval, maxval, maxbpn, mapped; } ch[2]; };
 // walks the frame records (WriteEncoded layout: u32 numsamples, 58 x f32 profile, per channel u32 blocksize, mean, min,
 // max, u16 flag (bit 9 = mapped, low byte = maxbpn), payload); false on a truncated file

@@ -637,3 +637,30 @@ def test_de_and_cma_searches_write_the_reference_records(api, golden_r4, name):
     costs = ctx.evaluate(g, np.zeros(len(tcost), np.int32), tcoefs)
     assert np.allclose(costs, tcost, rtol=1e-9, atol=0)
     ctx.close()
+
+
+def test_decode_cli_restores_the_wav_files(api, tmp_path):
+    """--decode (cmdline.cpp:295-358 + Codec::DecodeFile, libsac.cpp:857-883) on the GPU decoder: sacenc --decode and
+    `python -m sac_amd.cli decode` rebuild byte-identical WAV files (16-bit stereo with a LIST chunk behind the data; 8-bit
+    mono with an odd number of sample bytes, i.e. with the pad byte), Audio MD5 ok."""
+    import os, subprocess, sys
+    from sac_amd import container as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "sac_amd", "sacenc")
+    rate, maxlen = RATE, 2
+    a = C.wav_bytes_from_pcm(synth_pcm(5 * rate + 13, 2, 501, rate), rate, 16)
+    a = a + b"LIST" + (10).to_bytes(4, "little") + b"INFOabcdef"            # a chunk behind the data chunk
+    a = a[:4] + (len(a) - 8).to_bytes(4, "little") + a[8:]
+    b = C.wav_bytes_from_pcm(synth_pcm(3 * rate + 1, 1, 502, rate, bits=8), rate, 8)
+    for i, blob in enumerate((a, b)):
+        src = tmp_path / f"in{i}.wav"; src.write_bytes(blob)
+        sac = tmp_path / f"f{i}.sac"
+        subprocess.run([exe, "--high", "--opt-cfg=dds,4", f"--framelen={maxlen}", str(src), str(sac)], check=True)
+        out1 = tmp_path / f"cpp{i}.wav"
+        r = subprocess.run([exe, "--decode", str(sac), str(out1)], capture_output=True, text=True)
+        assert r.returncode == 0 and "Audio MD5: ok" in r.stdout, r.stdout + r.stderr
+        assert out1.read_bytes() == blob
+        out2 = tmp_path / f"py{i}.wav"
+        r = subprocess.run([sys.executable, "-m", "sac_amd.cli", "decode", str(sac), str(out2)], capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0 and "Audio MD5: ok" in r.stdout, r.stdout + r.stderr
+        assert out2.read_bytes() == blob
