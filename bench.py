@@ -498,10 +498,13 @@ def main():
         fam = "k_ols" if kt["ols"]["ms"] >= max(kt["lms"]["ms"], kt["coder"]["ms"]) else ("k_lms" if kt["lms"]["ms"] >= kt["coder"]["ms"] else "k_coder")
         dom = max((k for k in cands if k.startswith(fam)), key=lambda k: cands[k][0])
         dms, dlaunch, dbytes, disteps, dflops = cands[dom]
-        # HBM traffic per item-step of that kernel from the committed PMC pass (profiles/r02/pmc_hbm.json), if present
+        # HBM traffic per item-step of that kernel from the newest committed PMC pass (profiles/rNN/pmc_hbm.json), if present
         traffic = None
+        pmc_src = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_hbm.json")))
+            import glob
+            pmc_src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_hbm.json")))[-1]
+            pm = json.load(open(pmc_src))
             ent = pm["kernels"].get(dom.split(" (")[0])
             if ent and disteps > 0:
                 traffic = (ent["fetch_bytes_per_item_step"] + ent["write_bytes_per_item_step"]) * disteps / max(dlaunch, 1)
@@ -515,8 +518,9 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc pass on a smaller batch (profiles/r02/pmc_hbm.json: "
-                            "FETCH_SIZE + WRITE_SIZE per item-step of this kernel, scaled to this run's item-steps per launch); null = not collected",
+            "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes on a smaller batch of full-length frames ("
+                            + (os.path.relpath(pmc_src, ROOT) if pmc_src else "none found") +
+                            ": FETCH_SIZE + WRITE_SIZE per item-step of this kernel, scaled to this run's item-steps per launch); null = not collected",
             "launches": int(dlaunch), "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": dbytes / max(dlaunch, 1),
             "binds": "LDS instruction issue + dependent fp64 latency (neither HBM nor MFMA: ~1e4 flop/B, contractions <= 96 wide)",
             "fp64": {"kernel_gflops": dflops / (dms / 1e3) / 1e9 if dms > 0 else 0.0,

@@ -127,7 +127,8 @@ struct sacamd_ctx {
   // coder
   DevBuf<unsigned short> d_laplace, d_inv;
   DevBuf<short> d_fwd;
-  DevBuf<unsigned char> d_cstate, d_cout;
+  DevBuf<unsigned char> d_cstate, d_cout, d_ccompact;   // d_ccompact: payloads back to back in completion order
+  DevBuf<long long> d_cat;                               // their offsets + bytes used
   DevBuf<int> d_clen;
   DevBuf<CoderJob> d_jobs;
   DevBuf<RemapJob> d_rj;
@@ -627,7 +628,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
   c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
-  c->d_cout.release(); c->d_clen.release(); c->d_jobs.release();
+  c->d_cout.release(); c->d_clen.release(); c->d_jobs.release(); c->d_ccompact.release(); c->d_cat.release();
   c->d_rj.release(); c->d_declink.release(); c->d_decprog.release(); if (c->h_started) (void)hipHostFree(c->h_started); c->d_prefix.release(); c->d_tmp_s2u.release(); c->d_tmp_mb.release(); c->d_out3.release();
   delete c;
 }

@@ -51,14 +51,17 @@ void launch_sparse_cost(hipStream_t s, const int *d_pcm, const long long *d_off,
 struct CoderJob {
   long long off_in;     // ints into d_s2u
   long long off_out;    // bytes into d_out
-  int n, maxbpn;
+  int n, maxbpn;        // maxbpn < 0: taken from the device array d_maxbpn[-1 - maxbpn] (written by k_s2u earlier on the stream)
   int cap;              // output capacity in bytes
   int with_map;         // 1: MapEncoder prefix over used flags
   long long off_used;   // bytes into d_used (usedl at +0 .. usedh at +32769)
 };
 void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map /*jobs with_map*/, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv,
-                  unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len);
+                  unsigned char *d_state, size_t state_stride, unsigned char *d_out, int *d_len,
+                  const int *d_maxbpn = nullptr /*for jobs with maxbpn < 0*/,
+                  unsigned char *d_compact = nullptr /*nullable: every finished stream appends its payload here (16-byte aligned)*/,
+                  long long *d_compact_at = nullptr /*[count] offset of each payload in d_compact, [count] = bytes used (zeroed by the launcher)*/);
 size_t coder_state_bytes();
 struct DecJob {
   long long off_in;     // bytes into d_in (the channel's payload)

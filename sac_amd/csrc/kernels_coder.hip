@@ -23,7 +23,8 @@ size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
 
 __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJob *jobs, int count, const int *s2u, const int *s2u_map, const unsigned char *used,
                                                const unsigned short *laplace, const short *gfwd, const unsigned short *ginv,
-                                               unsigned char *state, size_t stride, unsigned char *out, int *len) {
+                                               unsigned char *state, size_t stride, unsigned char *out, int *len,
+                                               const int *mb, unsigned char *compact, long long *compact_at) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
   coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, (int)blockDim.x);
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJo
   const int wave = threadIdx.x >> 6;
   const int ji = blockIdx.x * (int)(blockDim.x >> 6) + wave;
   if (ji >= count) return;                       // no further workgroup-wide barriers below
-  const CoderJob job = jobs[ji];
+  CoderJob job = jobs[ji];
+  if (job.maxbpn < 0) job.maxbpn = mb[-1 - job.maxbpn];
   char *sb = smem + CoderLdsLayout::o_stream + (size_t)wave * CoderLdsLayout::s_total;
   CoderModel &M = *reinterpret_cast<CoderModel *>(sb + CoderLdsLayout::s_model);
   CoderWin &W = *reinterpret_cast<CoderWin *>(sb + CoderLdsLayout::s_win);
@@ -42,13 +44,29 @@ __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJo
   const int *src = job.with_map ? s2u_map : s2u;       // remapped residual stream for the MapEncoder variant
   const int l = coder_stream(ex, src + job.off_in, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace, gfwd, ginv,
                              plap, csig0, out + job.off_out, job.cap, M, T, W, MM);
-  if ((threadIdx.x & 63) == 0) len[ji] = l;
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) len[ji] = l;
+  if (compact) {
+    // the finished payload moves behind the payloads finished so far: the host then fetches ONE contiguous block instead of
+    // one copy per stream out of the sparsely filled capacity buffers
+    const int lw = __builtin_amdgcn_readfirstlane(l);
+    const int keep = lw < job.cap ? lw : job.cap;
+    long long at = 0;
+    if (lane == 0) { at = (long long)atomicAdd((unsigned long long *)&compact_at[count], (unsigned long long)((keep + 15) & ~15)); compact_at[ji] = at; }
+    at = __shfl(at, 0, 64);
+    __threadfence();
+    const unsigned char *src = out + job.off_out;
+    for (int i = lane * 16; i < keep; i += 64 * 16) {     // off_out and at are multiples of 16; capacities are padded to 16
+      *reinterpret_cast<uint4 *>(compact + at + i) = *reinterpret_cast<const uint4 *>(src + i);
+    }
+  }
 }
 
 void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d_s2u, const int *d_s2u_map, const unsigned char *d_used,
                   const unsigned short *d_laplace, const short *d_fwd, const unsigned short *d_inv, unsigned char *d_state,
-                  size_t state_stride, unsigned char *d_out, int *d_len) {
+                  size_t state_stride, unsigned char *d_out, int *d_len, const int *d_maxbpn, unsigned char *d_compact, long long *d_compact_at) {
   if (count <= 0) return;
+  if (d_compact && hipMemsetAsync(d_compact_at + count, 0, sizeof(long long), s) != hipSuccess) return;
   {   // per DEVICE opt-in to > 64 KB dynamic LDS (idempotent; launchers may be called from several host threads)
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
@@ -68,7 +86,7 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   if (count > 512) { spw = 3; while (spw < kCoderStreamsPerWg && count > 256 * spw) spw++; }
   const int wgs = (count + spw - 1) / spw;
   hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_s2u_map, d_used, d_laplace,
-                     d_fwd, d_inv, d_state, state_stride, d_out, d_len);
+                     d_fwd, d_inv, d_state, state_stride, d_out, d_len, d_maxbpn, d_compact, d_compact_at);
 }
 
 // ------------------------------------------------------------------ entropy DEcoder (FrameCoder::DecodeMonoFrame, libsac.cpp:280-298)

@@ -113,6 +113,28 @@ def main_r4():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def main_r5():
+    """tests/golden/ref_golden_r5.npz (round 3): BASELINE configs[3] (--best) and configs[4] (--veryhigh, 8-bit mono and
+    16-bit stereo) on full-size frames with a reduced evaluation count: record SHA-256 + length + chosen profile + search costs."""
+    import hashlib, time
+    from golden_cases import FULL_FRAMESIZE, config34_cases
+    R = Checker("ref")
+    out = {}
+    for name, (raw, cfg) in config34_cases().items():
+        t = time.time()
+        r = R.encode_frame(raw, cfg, FULL_FRAMESIZE, trace=True)
+        out[f"cfg/{name}/raw_sha256"] = np.frombuffer(hashlib.sha256(raw.astype(np.int16).tobytes()).digest(), np.uint8)
+        out[f"cfg/{name}/record_sha256"] = np.frombuffer(hashlib.sha256(r["record"]).digest(), np.uint8)
+        out[f"cfg/{name}/record_len"] = np.array([len(r["record"])], np.int64)
+        out[f"cfg/{name}/profile"] = r["profile"]
+        out[f"cfg/{name}/trace_cost"] = r["trace_cost"]
+        out[f"cfg/{name}/cpu_seconds"] = np.array([time.time() - t])
+        print(name, len(r["record"]), "bytes", round(time.time() - t, 1), "s on one core")
+    path = os.path.join(HERE, "ref_golden_r5.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     R = Checker("ref")
     out = {}
@@ -198,5 +220,7 @@ if __name__ == "__main__":
         main_r3()
     elif "--r4" in sys.argv:
         main_r4()
+    elif "--r5" in sys.argv:
+        main_r5()
     else:
         main()

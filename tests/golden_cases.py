@@ -126,6 +126,18 @@ def fullsize_cases():
     return c
 
 
+def config34_cases():
+    """BASELINE configs[3] and [4] at their real sizes with the evaluation count cut (the window and cost are what make
+    them different from configs[2]): name -> (raw PCM, FrameCfg).
+    best_s16: --best (CostBitplane objective over a 441 000-sample window, sigma 0.25), 17 evaluations (dds,8).
+    vh_m8 / vh_s16: --veryhigh (176 400-sample window), 8-bit mono and 16-bit stereo material, 25 evaluations."""
+    c = {}
+    c["best_s16_e17"] = (synth_pcm(20 * FULL_RATE, 2, 3000, FULL_RATE), frame_cfg("best", num_threads=8, maxnfunc=17))
+    c["vh_m8_e25"] = (synth_pcm(20 * FULL_RATE, 1, 3100, FULL_RATE, bits=8), frame_cfg("veryhigh", num_threads=8, maxnfunc=25))
+    c["vh_s16_e25"] = (synth_pcm(20 * FULL_RATE, 2, 3200, FULL_RATE), frame_cfg("veryhigh", num_threads=8, maxnfunc=25))
+    return c
+
+
 def subframe_cases():
     """name -> (pcm [nch,n] int32 raw, blocksamples, min_frame_length): material whose 3-"second"
     blocks alternate between dense and sparse (quantised) PCM, for Codec::Analyse / PushState."""
