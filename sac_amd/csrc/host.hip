@@ -169,6 +169,7 @@ struct sacamd_ctx {
   std::vector<TimedSpan> spans;
   std::vector<TraceSpan> trace;
   bool tracing = false;
+  hipEvent_t ev_epoch = nullptr;          // tracing: the first traced launch of the context (time origin of the printed starts)
   // [kind 0 = OLS classes 0..7, kind 1 = cascade classes 0..2][class] -> ms, launches, item-steps
   static constexpr int kClsMax = 16;   // >= kNumOlsClasses, kNumLmsClasses
   double cls_ms[2][kClsMax] = {}, cls_item_steps[2][kClsMax] = {}, cls_flops[2][kClsMax] = {};
@@ -217,7 +218,11 @@ void collect_spans(sacamd_ctx *c) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
       c->cls_ms[t.kind][t.cls] += ms; c->cls_launches[t.kind][t.cls]++; c->cls_item_steps[t.kind][t.cls] += t.item_steps; c->cls_flops[t.kind][t.cls] += t.flops;
-      if (c->tracing) std::fprintf(stderr, "[sacamd trace] %s %.3f ms\n", t.label, ms);
+      if (c->tracing) {
+        float at = 0;
+        if (c->ev_epoch) (void)hipEventElapsedTime(&at, c->ev_epoch, t.a);
+        std::fprintf(stderr, "[sacamd trace] %s %.3f ms (start +%.1f ms)\n", t.label, ms, at);
+      }
     }
     c->put_event(t.a); c->put_event(t.b);
   }
@@ -232,6 +237,7 @@ struct Trace {
     std::snprintf(t.label, sizeof(t.label), "%s class %d items %d steps %d", what, cls, count, n);
     t.kind = what[0] == 'o' ? 0 : 1; t.cls = cls; t.item_steps = item_steps; t.flops = flops;
     t.a = c->get_event(); t.b = c->get_event();
+    if (c->tracing && !c->ev_epoch && hipEventCreate(&c->ev_epoch) == hipSuccess) (void)hipEventRecord(c->ev_epoch, st);
     (void)hipEventRecord(t.a, st);
   }
   ~Trace() { if (on) { (void)hipEventRecord(t.b, st); c->trace.push_back(t); } }
@@ -432,11 +438,17 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // class lists, heaviest first.  Cascade items are additionally split by how long their OLS class
   // runs (group 0: one-wave classes <= 32 taps, group 1: the panel classes): a cascade launch only
   // waits for the OLS classes of its own group, so cascade work starts under the OLS tail.
-  constexpr int kFastOls = 3;                       // OLS classes [0, kFastOls) form group 0
-  std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][2];
+  // The final pass (one evaluation, latency-bound: a frame's OLS class decides when its p_lpc stream is complete, 9 s for
+  // 16 taps to 40 s for 56..64 taps on a 20-s frame) groups by OLS class instead, so that the cascade of a frame starts when
+  // ITS OLS kernel has ended and the last cascade launch holds only the frames of the slowest class.
+  constexpr int kFastOls = 3;                       // search: OLS classes [0, kFastOls) form group 0
+  static const bool fine_groups = [] { const char *e = std::getenv("SACAMD_FINAL_GROUPS"); return !(e && e[0] == '0'); }();
+  const int ngroups = (want_pred && fine_groups) ? kNumOlsClasses : 2;
+  auto group_of_class = [&](int ols_class) { return ngroups == 2 ? (ols_class >= kFastOls ? 1 : 0) : ols_class; };
+  std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][kNumOlsClasses];
   for (int i = 0; i < count; i++) {
     if (ols_lead[i] == i && !ols_skip[i]) idx_ols[items[i].ols_class].push_back(i);
-    idx_lms[items[i].lms_class][items[ols_lead[i]].ols_class >= kFastOls].push_back(i);
+    idx_lms[items[i].lms_class][group_of_class(items[ols_lead[i]].ols_class)].push_back(i);
   }
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
@@ -455,7 +467,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // workgroup fit on a CU (160 KB LDS); tiers are independent launches.
   struct LmsLaunch { int cls, group, first, count; LmsRingCap rc; };
   std::vector<LmsLaunch> lms_launches;
-  for (int g = 0; g < 2; g++)
+  for (int g = 0; g < ngroups; g++)
     for (int k = 0; k < kNumLmsClasses; k++) {
       std::vector<int> &v = idx_lms[k][g];
       const int m = (int)v.size();
@@ -524,8 +536,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     const int si = kNumOlsClasses + (int)(q % kLmsStreams);
     hipStream_t st = c->cls_stream[si];
     if (!lms_used[si]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); lms_used[si] = true; }
-    for (int k = ll.group ? kFastOls : 0; k < (ll.group ? kNumOlsClasses : kFastOls); k++)
-        if (!idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
+    for (int k = 0; k < kNumOlsClasses; k++)
+      if (group_of_class(k) == ll.group && !idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
     double isteps = 0, fl = 0; for (int i = 0; i < ll.count; i++) if (flat[ll.first + i] >= 0) { isteps += items[flat[ll.first + i]].n; fl += lms_flops(items[flat[ll.first + i]]); }
     Trace tr(c, st, "lms", ll.cls, ll.count, (int)(lms_lds_bytes(ll.cls, ll.rc) / 1024), isteps, fl);
     launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, pv, c->d_tab.p, c->d_p.p, c->d_q.p);
