@@ -696,7 +696,7 @@ struct Bitplane {
   int *pabuf = nullptr;
   CntLimit *pl, *pc1, *pc2, *pc3, *pc4; Mixer *plmix; SSENL<15> *ps1, *ps2;
 
-  Bitplane(int maxbpn_, int n) : maxbpn(maxbpn_), numsamples(n), csig0(1 << 16), csig1(80), cref0(32), cref1(256), cref2(64), cref3(160), sse(160), msb(n, 0) {
+  Bitplane(int maxbpn_, int n) : maxbpn(maxbpn_), numsamples(n), csig0(1 << 16), csig1(80), cref0(32), cref1(256), cref2(64), cref3(256), sse(160), msb(n, 0) {
     for (auto &m : lmixref) m.n = 5;
     for (auto &m : lmixsig) m.n = 3;
     ssemix.n = 2;

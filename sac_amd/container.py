@@ -119,8 +119,11 @@ def pcm_from_wav(w: WavInfo) -> np.ndarray:
         a = np.frombuffer(w.data, np.uint8).astype(np.int32) - 128
     elif csize == 2:
         a = np.frombuffer(w.data, "<i2").astype(np.int32)
+    elif csize == 3:                                    # wav.cpp:109-121: three little-endian bytes, sign from the top one
+        b = np.frombuffer(w.data, np.uint8).reshape(-1, 3).astype(np.int32)
+        a = ((b[:, 0] << 8) | (b[:, 1] << 16) | (b[:, 2] << 24)) >> 8
     else:
-        raise ValueError("only 8- and 16-bit PCM are in scope of the GPU path")
+        raise ValueError("unsupported sample size (8-, 16- and 24-bit PCM)")
     return np.ascontiguousarray(a.reshape(-1, w.numchannels).T)
 
 
@@ -140,8 +143,8 @@ def wav_bytes_from_pcm(pcm: np.ndarray, rate: int, bits: int = 16, extra_chunks=
     """A plain PCM WAV (tests / synthetic inputs)."""
     pcm = np.asarray(pcm)
     nch, n = pcm.shape
-    data = ((pcm.T + 128).astype(np.uint8) if bits == 8 else pcm.T.astype("<i2")).tobytes()
-    csize = 1 if bits == 8 else 2
+    data = sample_bytes(pcm, bits)
+    csize = (bits + 7) // 8
     fmt = struct.pack("<HHIIHH", 1, nch, rate, rate * nch * csize, nch * csize, bits)
     body = b"WAVE" + struct.pack("<II", ID_FMT, 16) + fmt
     for cid, payload in extra_chunks:

@@ -17,6 +17,7 @@
 #pragma once
 #include <type_traits>
 #include "simt.h"
+#include "libm_port.h"
 
 namespace sacamd {
 
@@ -206,6 +207,18 @@ SA_HD int msb_seen(const CoderWin &W, int li, bool before, int bpn) {
   return before ? (m >= bpn ? m : 0) : (m > bpn ? m : 0);
 }
 
+// BitplaneCoder::PredictLaplace (vle.cpp:70-79) evaluated directly, for the (avg_sum, plane) pairs the host table does not
+// hold: avg_sum >= 2^17 or plane >= 18, i.e. material wider than 16 bits.  exp / pow are the glibc ports of libm_port.h, so
+// the value is the one the table would hold.
+SA_HD int laplace_direct(unsigned avg, int bpn) {
+  double p_l = 0.0;
+  if (avg > 0) {
+    const double theta = sa_exp(-1.0 / (double)avg);
+    p_l = 1.0 - 1.0 / (1 + sa_pow(theta, (double)(1 << bpn)));
+  }
+  return clampi((int)round(p_l * kPScale), 1, kPScaleM);
+}
+
 SA_HD CoderDescR coder_describe(const CoderWin &W, const CoderTabs &T, int i, int s, int n, int bpn, const unsigned short *laplace) {
   const int li = i + kCoderHalo;
   // GetAvgSum(32), vle.cpp:54-68
@@ -216,7 +229,7 @@ SA_HD CoderDescR coder_describe(const CoderWin &W, const CoderTabs &T, int i, in
     if (k >= 0 && k < n) { nsum += (unsigned)W.val[li + d] & (d < 0 ? ml : mr); nidx++; }
   }
   const unsigned avg = nidx > 0 ? (unsigned)((nsum + (nidx - 1)) / nidx) : 0;
-  const int pest = laplace[(size_t)bpn * kLaplaceAvg + (avg < (unsigned)kLaplaceAvg ? avg : (unsigned)kLaplaceAvg - 1)];
+  const int pest = (avg < (unsigned)kLaplaceAvg && bpn < kLaplacePlanes) ? laplace[(size_t)bpn * kLaplaceAvg + avg] : laplace_direct(avg, bpn);
   // GetSigState, vle.cpp:33-52
   int sig[17];
   sig[0] = msb_seen(W, li, false, bpn);
@@ -244,6 +257,7 @@ SA_HD CoderDescR coder_describe(const CoderWin &W, const CoderTabs &T, int i, in
     i1 = sig[0]; i2 = ctx1 & 255;
     i3 = (c0 + (c1 << 1) + (c2 << 2) + (c3 << 3)) + (d0 << 4) + (d1 << 5);
     i4 = sig[1] + sig[2] + sig[3] + sig[4] + sig[5] + sig[6] + sig[7] + sig[8];
+    if (i4 > 159) i4 = 159;   // cref3 is updated but never predicts (vle.cpp:122,127,138): any slot does; 16-bit material stays below 137
     mix = ((((pest >> 12) << 1) + d0) << 1) + (b0 & 1);
   } else {
     // PredictSig + CountSig, vle.cpp:144-177

@@ -95,6 +95,7 @@ struct sacamd_ctx {
   hipStream_t stream = nullptr;
   static constexpr int kSide = 13;                 // logical side streams: 8 OLS classes + 4 cascade launches + 1 marker
   hipStream_t cls_stream[kSide] = {};
+  hipStream_t tail_stream[kSide] = {};             // the same roles for the final pass (so that one context's tail does not sit in the stream order of another context's search)
   // `cls_stream` come from the per-device pool (DevStreams below), shared by all contexts of the device
   hipStream_t own_main = nullptr;                  // this context's main stream (the side streams are pooled)
   hipEvent_t ev_fork = nullptr, ev_join[kSide] = {}, ev_ols[kNumOlsClasses] = {};
@@ -119,7 +120,7 @@ struct sacamd_ctx {
   DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist, d_nf;   // d_nf: per work-item "prediction not finite" flags of the last run_predict
   std::vector<int> h_nf;
   DevBuf<double> d_tab, d_p, d_q, d_cost;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
-  DevBuf<long long> d_off;
+  DevBuf<long long> d_off, d_hoff;
   // final pass products (per frame, channel): offsets (f*nch+ch)*ch_stride
   DevBuf<int> d_ferr, d_fpred, d_fs2u, d_fs2u_map, d_maxbpn;
   std::vector<int> h_maxbpn;
@@ -259,7 +260,7 @@ PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_
 // context that recorded it.
 struct DevStreams {
   bool ready = false;
-  hipStream_t lo_main = nullptr, lo_cls[sacamd_ctx::kSide] = {};
+  hipStream_t lo_main = nullptr, lo_cls[sacamd_ctx::kSide] = {}, lo_tail[sacamd_ctx::kSide] = {};
   // One search at a time per device: a batch's search saturates the chip on its own, and two searches issued to the
   // pooled streams would only queue behind each other's dependency chains.  What may overlap is the search of one
   // context with the latency-bound tail of another (sacamd_encode_frames releases this before its tail).
@@ -275,6 +276,16 @@ int ensure_dev_streams(int device) {
     if (hipStreamCreate(&d.lo_main) != hipSuccess) return SACAMD_ERR_HIP;
     for (int k = 0; k < sacamd_ctx::kSide; k++)
       if (hipStreamCreate(&d.lo_cls[k]) != hipSuccess) return SACAMD_ERR_HIP;
+    // The final pass gets its own set when SACAMD_TAIL_STREAMS=1 (software-pipelined batches: bench.py --pipeline 2): its
+    // multi-second kernels would otherwise precede the next batch's search launches of the same class in stream order.
+    // Default: the same streams (a single context never overlaps its own search and tail, and fewer streams keep the
+    // hardware queues from being oversubscribed).
+    const char *e = std::getenv("SACAMD_TAIL_STREAMS");
+    const bool own_tail = e && e[0] == '1';
+    for (int k = 0; k < sacamd_ctx::kSide; k++) {
+      d.lo_tail[k] = d.lo_cls[k];
+      if (own_tail && hipStreamCreate(&d.lo_tail[k]) != hipSuccess) return SACAMD_ERR_HIP;
+    }
     d.ready = true;
   }
   return 0;
@@ -283,7 +294,7 @@ int ensure_dev_streams(int device) {
 void bind_streams(sacamd_ctx *c) {
   DevStreams &d = g_streams[c->device & 63];
   c->stream = c->own_main ? c->own_main : d.lo_main;
-  for (int k = 0; k < sacamd_ctx::kSide; k++) c->cls_stream[k] = d.lo_cls[k];
+  for (int k = 0; k < sacamd_ctx::kSide; k++) { c->cls_stream[k] = d.lo_cls[k]; c->tail_stream[k] = d.lo_tail[k]; }
 }
 
 // ------------------------------------------------------------ work-item construction
@@ -361,6 +372,7 @@ std::vector<int> xcd_interleave(const std::vector<int> &v, const std::vector<Wor
 
 // run the three predictor stages for `items`; residual -> d_err (+ d_pred when want_pred)
 int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
+  hipStream_t *side = want_pred ? c->tail_stream : c->cls_stream;
   const int count = (int)items.size();
   if (!count) return 0;
   long long tot_p = 0, tot_tab = 0;
@@ -511,11 +523,11 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, hipEventRecord(sp_ols.a, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   constexpr int kMark = sacamd_ctx::kSide - 1, kLmsStreams = sacamd_ctx::kSide - 1 - kNumOlsClasses;
-  HIPCHK(c, hipStreamWaitEvent(c->cls_stream[kMark], c->ev_fork, 0));
+  HIPCHK(c, hipStreamWaitEvent(side[kMark], c->ev_fork, 0));
   for (int q = 0; q < kNumOlsClasses; q++) {
     const int k = kNumOlsClasses - 1 - q;            // heaviest class first: its items are the long pole
     if (idx_ols[k].empty()) continue;
-    hipStream_t st = c->cls_stream[k];
+    hipStream_t st = side[k];
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     {
       double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
@@ -525,16 +537,16 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, want_pred);
     }
     HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
-    HIPCHK(c, hipStreamWaitEvent(c->cls_stream[kMark], c->ev_ols[k], 0));
+    HIPCHK(c, hipStreamWaitEvent(side[kMark], c->ev_ols[k], 0));
   }
-  HIPCHK(c, hipEventRecord(sp_ols.b, c->cls_stream[kMark]));
-  HIPCHK(c, hipEventRecord(c->ev_join[kMark], c->cls_stream[kMark]));
+  HIPCHK(c, hipEventRecord(sp_ols.b, side[kMark]));
+  HIPCHK(c, hipEventRecord(c->ev_join[kMark], side[kMark]));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[kMark], 0));
   bool lms_used[sacamd_ctx::kSide] = {};
   auto launch_one = [&](size_t q) -> int {
     const LmsLaunch &ll = lms_launches[q];
     const int si = kNumOlsClasses + (int)(q % kLmsStreams);
-    hipStream_t st = c->cls_stream[si];
+    hipStream_t st = side[si];
     if (!lms_used[si]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); lms_used[si] = true; }
     for (int k = 0; k < kNumOlsClasses; k++)
       if (group_of_class(k) == ll.group && !idx_ols[k].empty()) HIPCHK(c, hipStreamWaitEvent(st, c->ev_ols[k], 0));
@@ -545,7 +557,7 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   };
   for (size_t q = 0; q < lms_launches.size(); q++) { int r = launch_one(q); if (r) return r; }
   for (int si = kNumOlsClasses; si < kMark; si++)
-    if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], c->cls_stream[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
+    if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], side[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
   HIPCHK(c, hipEventRecord(sp_lms.b, c->stream));
   sp_lms.a = sp_ols.b;                               // cascade span = what is left after the last OLS kernel ended
   sp_lms.shared_a = true;
@@ -638,7 +650,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
   c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
-  c->d_off.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
+  c->d_off.release(); c->d_hoff.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release(); c->d_ccompact.release(); c->d_cat.release();
   c->d_rj.release(); c->d_declink.release(); c->d_decprog.release(); if (c->h_started) (void)hipHostFree(c->h_started); c->d_prefix.release(); c->d_tmp_s2u.release(); c->d_tmp_mb.release(); c->d_out3.release();
@@ -755,7 +767,38 @@ int run_costs(sacamd_ctx *c, int kind, const std::vector<long long> &off, const 
   { Span sp(c, FAM_COST); launch_cost(c->stream, kind, d_err, c->d_off.p, c->d_n.p, count, c->d_hist.p, c->d_cost.p); }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(out.data(), c->d_cost.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
-  return sync_stream(c);
+  int r = sync_stream(c);
+  if (r || kind != 2) return r;
+  // Entropy of residuals whose range exceeds the default histogram (material wider than 16 bits): the kernel reported
+  // -(range); those vectors run again, a few at a time, with histograms of their own size.
+  std::vector<int> wide;
+  for (int i = 0; i < count; i++) if (out[i] < 0.0) wide.push_back(i);
+  constexpr long long kTierInts = 1LL << 29;                     // 2 GB of histogram scratch per launch
+  for (size_t w0 = 0; w0 < wide.size();) {
+    std::vector<long long> o2, hoff, hcap; std::vector<int> n2; std::vector<int> which;
+    long long used = 0;
+    while (w0 < wide.size()) {
+      const long long range = (long long)(-out[wide[w0]]);
+      if (!which.empty() && used + range > kTierInts) break;
+      if (range > 0x7fffffffLL) return fail(c, SACAMD_ERR_ARG, "residual range beyond 31 bits");
+      which.push_back(wide[w0]); o2.push_back(off[wide[w0]]); n2.push_back(n[wide[w0]]); hoff.push_back(used); hcap.push_back(range);
+      used += range; w0++;
+    }
+    const int m = (int)which.size();
+    HIPCHK(c, c->d_hist.ensure((size_t)used + 16)); HIPCHK(c, c->d_hoff.ensure((size_t)2 * m));
+    HIPCHK(c, hipMemcpyAsync(c->d_off.p, o2.data(), sizeof(long long) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_n.p, n2.data(), sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_hoff.p, hoff.data(), sizeof(long long) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_hoff.p + m, hcap.data(), sizeof(long long) * m, hipMemcpyHostToDevice, c->stream));
+    { Span sp(c, FAM_COST); launch_cost(c->stream, kind, d_err, c->d_off.p, c->d_n.p, m, c->d_hist.p, c->d_cost.p, c->d_hoff.p, c->d_hoff.p + m); }
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> o(m);
+    HIPCHK(c, hipMemcpyAsync(o.data(), c->d_cost.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+    r = sync_stream(c);
+    if (r) return r;
+    for (int i = 0; i < m; i++) { if (o[i] < 0.0) return fail(c, SACAMD_ERR_STATE, "wide-range entropy pass failed"); out[which[i]] = o[i]; }
+  }
+  return 0;
 }
 }  // namespace
 
@@ -1010,12 +1053,37 @@ API int sacamd_plan_subframes(sacamd_ctx *c, const int32_t *pcm, long long ch_st
   HIPCHK(c, hipMemcpyAsync(sums.data(), c->d_out3.p, sizeof(long long) * sums.size(), hipMemcpyDeviceToHost, c->stream));
   int r = sync_stream(c);
   if (r) return r;
+  {   // blocks whose value range exceeds the LDS bitmap (material wider than 16 bits): second pass with bitmaps in global memory
+    std::vector<int> wide;
+    for (int j = 0; j < jobs; j++) if (sums[(size_t)j * 4 + 3] < 0) wide.push_back(j);
+    if (!wide.empty()) {
+      const int m = (int)wide.size();
+      std::vector<long long> o2(m), wd((size_t)2 * m);
+      std::vector<int> n2(m);
+      long long words = 0;
+      for (int i = 0; i < m; i++) {
+        const long long range = sums[(size_t)wide[i] * 4 + 2], need = 2 * ((range + 31) >> 5) + 1;
+        o2[i] = off[wide[i]]; n2[i] = nn[wide[i]]; wd[2 * i] = words; wd[2 * i + 1] = need; words += need;
+      }
+      HIPCHK(c, c->d_hist.ensure((size_t)words + 16)); HIPCHK(c, c->d_hoff.ensure((size_t)2 * m));
+      HIPCHK(c, hipMemcpyAsync(c->d_off.p, o2.data(), sizeof(long long) * m, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_n.p, n2.data(), sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_hoff.p, wd.data(), sizeof(long long) * 2 * m, hipMemcpyHostToDevice, c->stream));
+      { Span sp(c, FAM_ANALYSE); launch_sparse_cost(c->stream, c->d_plan_pcm.p, c->d_off.p, c->d_n.p, m, c->d_out3.p, reinterpret_cast<unsigned *>(c->d_hist.p), c->d_hoff.p); }
+      HIPCHK(c, hipGetLastError());
+      std::vector<long long> s2((size_t)m * 4);
+      HIPCHK(c, hipMemcpyAsync(s2.data(), c->d_out3.p, sizeof(long long) * s2.size(), hipMemcpyDeviceToHost, c->stream));
+      r = sync_stream(c);
+      if (r) return r;
+      for (int i = 0; i < m; i++) std::copy_n(&s2[(size_t)i * 4], 4, &sums[(size_t)wide[i] * 4]);
+    }
+  }
   std::vector<int> state(nblocks);
   for (int b = 0; b < nblocks; b++) {
     double avg_cost = 0;
     for (int ch = 0; ch < nch; ch++) {
       const long long *q = &sums[((size_t)b * nch + ch) * 4];
-      if (q[3] < 0) return fail(c, SACAMD_ERR_ARG, "sub-frame analysis: value range of a block exceeds 2^17");
+      if (q[3] < 0) return fail(c, SACAMD_ERR_ARG, "sub-frame analysis: value range of a block beyond 31 bits");
       // sparse.h:52-72: both sums are exact integers in the reference's doubles
       avg_cost += q[1] > 0 ? static_cast<double>(q[0]) / static_cast<double>(q[1]) : 0.0;
     }

@@ -42,11 +42,15 @@ void launch_dec_olsbias(hipStream_t s, const WorkItem *d_items, const int *d_idx
 void launch_used_prefix(hipStream_t s, int count, const unsigned char *d_used, const long long *d_off_used, int *d_prefix);
 // ---- costs / s2u (kernels_misc.hip)
 void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_off, const int *d_n, int count,
-                 int *d_hist_scratch, double *d_cost);
+                 int *d_hist_scratch, double *d_cost, const long long *d_hist_off = nullptr /*per-vector histogram start (ints)*/,
+                 const long long *d_hist_cap = nullptr /*and capacity; default: count x cost_hist_scratch_ints()*/);
 void launch_s2u(hipStream_t s, const int *d_err, int *d_s2u, const long long *d_off, const int *d_n, int count, int *d_maxbpn);
 size_t cost_hist_scratch_ints();
-// SparsePCM::Analyse sums per block: out4[4b..] = {sum|val|, sum|rank|, used values, range (-1: unsupported)}
-void launch_sparse_cost(hipStream_t s, const int *d_pcm, const long long *d_off, const int *d_n, int count, long long *d_out4);
+// SparsePCM::Analyse sums per block: out4[4b..] = {sum|val|, sum|rank|, used values, range}; range -1: the block's value range
+// (then in out4[4b+2]) exceeds the LDS bitmap -> run those blocks again with d_wide (per block: start and size, in 32-bit
+// words, of its bitmap + prefix scratch in d_scratch; needs 2 * ceil(range / 32) + 1 words)
+void launch_sparse_cost(hipStream_t s, const int *d_pcm, const long long *d_off, const int *d_n, int count, long long *d_out4,
+                        unsigned *d_scratch = nullptr, const long long *d_wide = nullptr);
 // ---- coder (kernels_coder.hip)
 struct CoderJob {
   long long off_in;     // ints into d_s2u

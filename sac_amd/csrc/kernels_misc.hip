@@ -81,46 +81,34 @@ void launch_analyse_i32(hipStream_t s, int nframes, int nch, const int *d_raw, l
 // [min, max] in LDS (16-bit material: <= 65536 values); range > kSparseMaxRange -> out[3] = -1.
 constexpr int kSparseMaxRange = 1 << 17;
 constexpr int kSparseWords = kSparseMaxRange / 32;
-__global__ __launch_bounds__(256) void k_sparse_cost(const int *pcm, const long long *off, const int *nn, long long *out) {
-  __shared__ unsigned bits[kSparseWords];
-  __shared__ int pre[kSparseWords + 1];
-  __shared__ int s_i[4];
+// the sums over one block of samples, given zeroed bitmap words `bits` [nw] and prefix storage `pre` [nw + 1] (LDS for
+// 16-bit material, global scratch for wider ranges)
+__device__ void sparse_cost_body(const int *x, int n, int mn, int N, unsigned *bits, int *pre, long long *o) {
+  __shared__ int part[256];
   __shared__ long long s_ll[4];
-  const int b = blockIdx.x;
-  const int *x = pcm + off[b];
-  const int n = nn[b];
-  long long *o = out + 4LL * b;
-  if (n <= 0) { if (threadIdx.x == 0) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; } return; }
-  int mn = 2147483647, mx = -2147483647 - 1;
-  for (int i = threadIdx.x; i < n; i += 256) { const int v = x[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-  mn = block_reduce(mn, s_i, [](int a, int c) { return a < c ? a : c; });
-  mx = block_reduce(mx, s_i, [](int a, int c) { return a > c ? a : c; });
-  const long long range = (long long)mx - mn + 1;
-  if (range > kSparseMaxRange) { if (threadIdx.x == 0) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = -1; } return; }
-  const int N = (int)range, nw = (N + 31) >> 5;
-  for (int i = threadIdx.x; i < nw; i += 256) bits[i] = 0u;
-  __syncthreads();
+  const int nw = (N + 31) >> 5;
   for (int i = threadIdx.x; i < n; i += 256) { const int t = x[i] - mn; atomicOr(&bits[t >> 5], 1u << (t & 31)); }
+  __threadfence_block();
   __syncthreads();
   // exclusive prefix of the per-word popcounts: each thread owns a contiguous run of words
-  const int per = (nw + 255) / 256, w0 = threadIdx.x * per, w1 = (w0 + per < nw) ? w0 + per : nw;
+  const int per = (nw + 255) / 256, w0 = threadIdx.x * per < nw ? threadIdx.x * per : nw, w1 = (w0 + per < nw) ? w0 + per : nw;
   int loc = 0;
   for (int w = w0; w < w1; w++) loc += __popc(bits[w]);
-  __shared__ int part[256];
   part[threadIdx.x] = loc;
   __syncthreads();
   if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; i++) { const int t = part[i]; part[i] = run; run += t; } pre[nw] = run; }
   __syncthreads();
   int run = part[threadIdx.x];
   for (int w = w0; w < w1; w++) { pre[w] = run; run += __popc(bits[w]); }
+  __threadfence_block();
   __syncthreads();
   auto prefix = [&](int idx) {           // number of used values with index < idx, idx in [0, N]
     const int w = idx >> 5, r = idx & 31;
     return pre[w] + (r ? __popc(bits[w] & ((1u << r) - 1u)) : 0);
   };
-  const int pidx = 0 - mn;
-  const int pa = prefix(pidx + 1 < 0 ? 0 : (pidx + 1 > N ? N : pidx + 1));
-  const int pb = prefix(pidx < 0 ? 0 : (pidx > N ? N : pidx));
+  const long long pidx = 0 - (long long)mn;
+  const int pa = prefix((int)(pidx + 1 < 0 ? 0 : (pidx + 1 > N ? N : pidx + 1)));
+  const int pb = prefix((int)(pidx < 0 ? 0 : (pidx > N ? N : pidx)));
   long long s0 = 0, s1 = 0;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int v = x[i];
@@ -133,9 +121,43 @@ __global__ __launch_bounds__(256) void k_sparse_cost(const int *pcm, const long 
   s1 = block_reduce(s1, s_ll, [](long long a, long long c) { return a + c; });
   if (threadIdx.x == 0) { o[0] = s0; o[1] = s1; o[2] = pre[nw]; o[3] = N; }
 }
-void launch_sparse_cost(hipStream_t s, const int *d_pcm, const long long *d_off, const int *d_n, int count, long long *d_out4) {
+
+// wide != nullptr: this launch is the second pass over the blocks whose range did not fit the LDS bitmap; wide[2b] = start
+// (32-bit words) of block b's scratch in `scratch` (bitmap words, then prefix ints), wide[2b+1] = words available
+__global__ __launch_bounds__(256) void k_sparse_cost(const int *pcm, const long long *off, const int *nn, long long *out, unsigned *scratch, const long long *wide) {
+  __shared__ unsigned bits[kSparseWords];
+  __shared__ int pre[kSparseWords + 1];
+  __shared__ int s_i[4];
+  const int b = blockIdx.x;
+  const int *x = pcm + off[b];
+  const int n = nn[b];
+  long long *o = out + 4LL * b;
+  if (n <= 0) { if (threadIdx.x == 0) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; } return; }
+  int mn = 2147483647, mx = -2147483647 - 1;
+  for (int i = threadIdx.x; i < n; i += 256) { const int v = x[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+  mn = block_reduce(mn, s_i, [](int a, int c) { return a < c ? a : c; });
+  mx = block_reduce(mx, s_i, [](int a, int c) { return a > c ? a : c; });
+  const long long range = (long long)mx - mn + 1;
+  if (!wide) {
+    if (range > kSparseMaxRange) { if (threadIdx.x == 0) { o[0] = 0; o[1] = 0; o[2] = range; o[3] = -1; } return; }   // -> second pass
+    const int N = (int)range, nw = (N + 31) >> 5;
+    for (int i = threadIdx.x; i < nw; i += 256) bits[i] = 0u;
+    __syncthreads();
+    sparse_cost_body(x, n, mn, N, bits, pre, o);
+  } else {
+    const long long nw = (range + 31) >> 5;
+    if (range > 0x7fffffe0LL || 2 * nw + 1 > wide[2 * b + 1]) { if (threadIdx.x == 0) { o[0] = 0; o[1] = 0; o[2] = range; o[3] = -2; } return; }
+    unsigned *gb = scratch + wide[2 * b];
+    for (long long i = threadIdx.x; i < nw; i += 256) gb[i] = 0u;
+    __threadfence_block();
+    __syncthreads();
+    sparse_cost_body(x, n, mn, (int)range, gb, reinterpret_cast<int *>(gb + nw), o);
+  }
+}
+void launch_sparse_cost(hipStream_t s, const int *d_pcm, const long long *d_off, const int *d_n, int count, long long *d_out4,
+                        unsigned *d_scratch, const long long *d_wide) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_sparse_cost, dim3(count), dim3(256), 0, s, d_pcm, d_off, d_n, d_out4);
+  hipLaunchKernelGGL(k_sparse_cost, dim3(count), dim3(256), 0, s, d_pcm, d_off, d_n, d_out4, d_scratch, d_wide);
 }
 
 // ------------------------------------------------------------------ cost functions (cost.h)
@@ -148,7 +170,11 @@ __device__ __forceinline__ int s2u_dev(int v) { return v < 0 ? 2 * (-v) : (v > 0
 // Entropy: order-0 histogram; the reference adds the per-bin terms sequentially, here each
 // thread adds its bins in order and the partials are combined in a fixed tree -> deterministic,
 // ~1e-15 relative from the reference's sequential sum (tolerance 1e-12 in the tests).
-__global__ __launch_bounds__(256) void k_cost(int kind, const int *err, const long long *off, const int *nn, int *hist_scratch, double *cost) {
+// hist_off / hist_cap (nullable): start and capacity (ints) of vector b's histogram in hist_scratch; default b * kHistGlobal
+// and kHistGlobal.  A residual range beyond the capacity (material wider than 16 bits) is not clamped: cost[b] = -(range) tells
+// the host to run that vector again with a histogram of its own size (entropy is never negative).
+__global__ __launch_bounds__(256) void k_cost(int kind, const int *err, const long long *off, const int *nn, int *hist_scratch, double *cost,
+                                              const long long *hist_off, const long long *hist_cap) {
   __shared__ long long s_ll[4];
   __shared__ int s_i[4];
   __shared__ double s_d[4];
@@ -172,15 +198,13 @@ __global__ __launch_bounds__(256) void k_cost(int kind, const int *err, const lo
   mn = block_reduce(mn, s_i, [](int a, int c) { return a < c ? a : c; });
   mx = block_reduce(mx, s_i, [](int a, int c) { return a > c ? a : c; });
   const long long range = (long long)mx - mn + 1;
-  int *hist = hist_scratch + (size_t)b * kHistGlobal;
-  const int nb = range < kHistGlobal ? (int)range : kHistGlobal;   // (larger ranges cannot occur for <=17-bit residuals)
+  int *hist = hist_scratch + (hist_off ? (size_t)hist_off[b] : (size_t)b * kHistGlobal);
+  const long long cap = hist_cap ? hist_cap[b] : (long long)kHistGlobal;
+  if (range > cap) { if (threadIdx.x == 0) cost[b] = -(double)range; return; }
+  const int nb = (int)range;
   for (int i = threadIdx.x; i < nb; i += 256) hist[i] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    long long k = (long long)e[i] - mn;
-    if (k >= kHistGlobal) k = kHistGlobal - 1;
-    atomicAdd(&hist[k], 1);
-  }
+  for (int i = threadIdx.x; i < n; i += 256) atomicAdd(&hist[(long long)e[i] - mn], 1);
   __syncthreads();
   const double invs = 1.0 / (double)n;
   double ent = 0.0;
@@ -214,10 +238,11 @@ __global__ void k_cost_golomb(const int *err, const long long *off, const int *n
   cost[b] = n ? nbits / 8. : 0.0;
 }
 
-void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_off, const int *d_n, int count, int *d_hist, double *d_cost) {
+void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_off, const int *d_n, int count, int *d_hist, double *d_cost,
+                 const long long *d_hist_off, const long long *d_hist_cap) {
   if (count <= 0) return;
   if (kind == 3) hipLaunchKernelGGL(k_cost_golomb, dim3((count + 63) / 64), dim3(64), 0, s, d_err, d_off, d_n, count, d_cost);
-  else hipLaunchKernelGGL(k_cost, dim3(count), dim3(256), 0, s, kind, d_err, d_off, d_n, d_hist, d_cost);
+  else hipLaunchKernelGGL(k_cost, dim3(count), dim3(256), 0, s, kind, d_err, d_off, d_n, d_hist, d_cost, d_hist_off, d_hist_cap);
 }
 
 // ------------------------------------------------------------------ S2U + maxbpn (libsac.cpp:429-441)

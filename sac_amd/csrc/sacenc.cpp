@@ -68,6 +68,8 @@ int main(int argc, char **argv) {
       }
       else if (a.rfind("--framelen=", 0) == 0) framelen = std::atoi(a.c_str() + 11);
       else if (a == "--adapt-block=no" || a == "--adapt-block=0") adapt_block = 0;
+      else if (a == "--sparse-pcm=no" || a == "--sparse-pcm=0") cfg.sparse_pcm = 0;                         // cmdline.cpp:187-190
+      else if (a == "--sparse-pcm" || a == "--sparse-pcm=yes" || a == "--sparse-pcm=1") cfg.sparse_pcm = 1;
       else if (a.rfind("--max-frames=", 0) == 0) max_frames = std::atoi(a.c_str() + 13);
       else if (a == "--header-only") header_only = true;
       else if (a == "--list") list_mode = 1;

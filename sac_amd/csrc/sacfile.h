@@ -87,7 +87,8 @@ inline std::vector<int32_t> pcm_from_wav(const WavInfo &w) {
       const uint8_t *p = &w.data[((size_t)i * nch + k) * cs];
       if (cs == 1) out[(size_t)k * n + i] = (int32_t)p[0] - 128;
       else if (cs == 2) out[(size_t)k * n + i] = (int16_t)(p[0] | (p[1] << 8));
-      else throw std::runtime_error("only 8- and 16-bit PCM are in scope of the GPU path");
+      else if (cs == 3) out[(size_t)k * n + i] = (int32_t)(((uint32_t)p[2] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[0] << 8)) >> 8;   // wav.cpp:109-121
+      else throw std::runtime_error("unsupported sample size (8-, 16- and 24-bit PCM)");
     }
   return out;
 }

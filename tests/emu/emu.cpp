@@ -3,6 +3,7 @@
 // `-m "not gpu"` suite check the kernels' logic (right-looking LDLT, fused NLMS sweep, ring
 // indexing, stereo geometry ...) against the oracle without a GPU.  The product never builds
 // or loads this file.
+#include <random>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -144,6 +145,22 @@ API int emu_bitplane(const int32_t *s2u, int n, int maxbpn, const unsigned char 
   int len = coder_stream(ex, s2u, n, maxbpn, used, lap.data(), gf.data(), gi.data(), plap, csig0.data(), out, cap, *M, *T, *W, *MM);
   delete M; delete T; delete W; delete MM;
   return len;
+}
+
+// laplace_direct (coder.h: PredictLaplace evaluated in the kernel for wide material) vs the host libm expression of the reference
+API long emu_laplace_mismatches(long n, int seed) {
+  std::mt19937_64 g(seed);
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    const int b = (int)(g() % 27);
+    const int ea = (int)(g() % 27);                       // avg spread over all magnitudes up to 2^27
+    const unsigned a = (unsigned)((g() % (1ull << ea)) + (i & 1 ? (1ull << ea) : 0));
+    double p_l = 0.0;
+    if (a > 0) { double theta = std::exp(-1.0 / a); p_l = 1.0 - 1.0 / (1 + std::pow(theta, (double)(1 << b))); }
+    const int want = std::min(std::max((int)std::round(p_l * kPScale), 1), (int)kPScaleM);
+    if (laplace_direct(a, b) != want) bad++;
+  }
+  return bad;
 }
 
 // decode side: bytes -> s2u values (+ used flags when with_map); returns bytes consumed

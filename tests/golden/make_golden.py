@@ -108,6 +108,16 @@ def main_r4():
         out[f"search/{name}/trace_cost"] = r["trace_cost"]
         out[f"search/{name}/trace_coefs"] = r["trace_coefs"]
         print(name, len(r["record"]), "bytes")
+    # 24-bit material (SURVEY 8f rank 3 remainder): raw as int32
+    from golden_cases import wide_cases
+    for name, (raw, cfg) in wide_cases().items():
+        r = R.encode_frame(raw, cfg, FRAMESIZE, trace=True)
+        out[f"wide/{name}/raw"] = raw.astype(np.int32)
+        out[f"wide/{name}/record"] = np.frombuffer(r["record"], np.uint8)
+        out[f"wide/{name}/profile"] = r["profile"]
+        out[f"wide/{name}/trace_cost"] = r["trace_cost"]
+        out[f"wide/{name}/trace_coefs"] = r["trace_coefs"]
+        print(name, len(r["record"]), "bytes", r["info"].tolist())
     path = os.path.join(HERE, "ref_golden_r4.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

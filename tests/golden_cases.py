@@ -99,6 +99,20 @@ def search_cases():
     return c
 
 
+def wide_cases():
+    """name -> (raw PCM, FrameCfg): 24-bit material (|sample| up to 2^23), encoded with --sparse-pcm=0 -- the reference's Remap
+    holds 2 x 32 769 used-value flags and prints "val too large" for every wider sample, so sparse-PCM mapping is a
+    16-bit feature; everything else on the path (predictor, Entropy / Bitplane cost over wide residual ranges, coder planes
+    above 17, PredictLaplace beyond the 2^17 table) is exercised here."""
+    c = {}
+    c["s24_normal"] = (synth_pcm(5000, 2, 91, RATE, bits=24), frame_cfg("normal", sparse_pcm=0))
+    c["s24_high_mt4"] = (synth_pcm(5000, 2, 91, RATE, bits=24), frame_cfg("high", num_threads=4, maxnfunc=12, sparse_pcm=0))
+    c["m24_bpncost_mt4"] = (synth_pcm(3000, 1, 92, RATE, bits=24), frame_cfg("high", num_threads=4, maxnfunc=9, cost=COST_BITPLANE, fraction=0.1, sparse_pcm=0))
+    loud = np.rint(np.random.default_rng(93).laplace(size=(1, 2500)) * 9e5).astype(np.int64)
+    c["m24_loud_noise_high"] = (np.clip(loud, -(1 << 23), (1 << 23) - 1).astype(np.int32), frame_cfg("high", num_threads=4, maxnfunc=9, sparse_pcm=0))
+    return c
+
+
 def search_quadratic_cases():
     """name -> (search, ndim, nfunc_max, sigma, seed) for the searchers on the analytic test function"""
     return {"de_56_100": (1, 56, 100, 0.2, 1), "de_13_500": (1, 13, 500, 0.2, 4), "de_3_31": (1, 3, 31, 0.2, 6), "de_56_20": (1, 56, 20, 0.2, 7),

@@ -110,6 +110,27 @@ def test_coder_body_emulated_vs_golden(emu, orc, golden):
     assert out[:n].tobytes() == golden["frame/sparse16_normal/record"].tobytes()[4 + 232 + 18:]
 
 
+def test_coder_body_on_wide_material_vs_oracle(emu, orc):
+    """Residuals wider than 16 bits: planes above 17 and avg_sum beyond the 2^17-entry table take PredictLaplace evaluated in
+    the kernel (laplace_direct: the glibc exp / pow ports) -- same value as the host libm expression for every (avg, plane),
+    same bytes as the oracle's coder, and the decoder body inverts them."""
+    emu.emu_laplace_mismatches.restype = ctypes.c_long
+    assert emu.emu_laplace_mismatches(1_000_000, 5) == 0
+    fwd, inv = orc.domain_tables()
+    rng = np.random.default_rng(7)
+    for scale, n in ((3e5, 3000), (2e6, 2500), (8e4, 1000)):
+        e = np.clip(np.rint(rng.laplace(size=n) * scale).astype(np.int64), -(1 << 23), (1 << 23) - 1).astype(np.int32)
+        u = np.where(e < 0, -2 * e, np.where(e > 0, 2 * e - 1, 0)).astype(np.int32)
+        mb = int(np.floor(np.log2(max(int(u.max()), 1))))
+        out = np.zeros(u.size * 4 + 70000, np.uint8)
+        ln = emu.emu_bitplane(_vp(u), u.size, mb, None, _vp(fwd), _vp(inv), _vp(out), out.size)
+        want = orc.bitplane_encode(u, mb)
+        assert out[:ln].tobytes() == want, (scale, mb)
+        dec = np.zeros(n, np.int32); pl = np.frombuffer(want, np.uint8).copy()
+        emu.emu_bitplane_decode(_vp(pl), pl.size, n, mb, None, _vp(fwd), _vp(inv), _vp(dec))
+        assert np.array_equal(dec, u)
+
+
 def test_host_dds_driver_matches_reference_search(emu, golden):
     nd = 12
     lo = np.zeros(nd); hi = np.arange(1, nd + 1) * 1.0

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from golden_cases import (FRAMESIZE, FULL_FRAMESIZE, RATE, chain_cases, frame_cases, fullsize_cases, rand_profile, search_cases,
-                          trace_cases, trace_cases_r2)
+                          trace_cases, trace_cases_r2, wide_cases)
 from oracle_api import center_frame, frame_cfg, ref_available
 from sac_amd.synth import synth_pcm
 
@@ -664,3 +664,46 @@ def test_decode_cli_restores_the_wav_files(api, tmp_path):
         r = subprocess.run([sys.executable, "-m", "sac_amd.cli", "decode", str(sac), str(out2)], capture_output=True, text=True, cwd=root)
         assert r.returncode == 0 and "Audio MD5: ok" in r.stdout, r.stdout + r.stderr
         assert out2.read_bytes() == blob
+
+
+@pytest.mark.parametrize("name", list(wide_cases().keys()))
+def test_24bit_material_records_vs_golden(api, golden_r4, name):
+    """24-bit material (|sample| up to 2^23, --sparse-pcm=0; SURVEY 8f rank 3 remainder): byte-identical frame records and
+    chosen profiles vs the genuine reference -- coder planes up to 24, PredictLaplace beyond the table, Entropy / Bitplane
+    search costs over residual ranges wider than the default histogram -- and the GPU decoder returns the input."""
+    raw, cfg = wide_cases()[name]
+    assert np.array_equal(raw, golden_r4[f"wide/{name}/raw"])
+    ctx = api.Context(raw.shape[0], FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    g = gpu_cfg(api, cfg)
+    recs, prof = ctx.encode_frames(g)
+    assert np.array_equal(prof[0], golden_r4[f"wide/{name}/profile"])
+    assert recs[0] == golden_r4[f"wide/{name}/record"].tobytes()
+    if cfg.optimize:
+        tcoefs = golden_r4[f"wide/{name}/trace_coefs"][: cfg.maxnfunc]; tcost = golden_r4[f"wide/{name}/trace_cost"][: cfg.maxnfunc]
+        ctx.upload_i32([raw], FRAMESIZE); ctx.analyse(g)
+        assert np.allclose(ctx.evaluate(g, np.zeros(len(tcost), np.int32), tcoefs), tcost, rtol=1e-9, atol=0)
+    dec, _ = ctx.decode_frames(recs, FRAMESIZE)
+    assert np.array_equal(dec[0], raw)
+    ctx.close()
+
+
+def test_24bit_subframe_plan_and_wav_roundtrip(api, orc, tmp_path):
+    """Sub-frame analysis over value ranges beyond the LDS bitmap (second pass with global-memory bitmaps) == Codec::Analyse,
+    and a 24-bit WAV through sacenc (--sparse-pcm=no) and back through sacenc --decode is byte-identical."""
+    import os, subprocess
+    from sac_amd import container as C
+    raw = synth_pcm(3 * 24000 + 500, 2, 95, RATE, bits=24)
+    raw[:, 24000:48000] = np.random.default_rng(5).integers(-100, 100, (2, 24000))
+    ctx = api.Context(2, 4 * 24000, 4)
+    plan = ctx.plan_subframes(raw, 24000, 24000)
+    assert plan == orc.plan_subframes(raw, 24000, 24000) and len(plan) == 3
+    ctx.close()
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sac_amd", "sacenc")
+    blob = C.wav_bytes_from_pcm(raw[:, :30000], RATE, 24)
+    src = tmp_path / "in24.wav"; src.write_bytes(blob)
+    sac = tmp_path / "f24.sac"; out = tmp_path / "out24.wav"
+    subprocess.run([exe, "--high", "--opt-cfg=dds,4", "--sparse-pcm=no", "--framelen=2", str(src), str(sac)], check=True)
+    r = subprocess.run([exe, "--decode", str(sac), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "Audio MD5: ok" in r.stdout, r.stdout + r.stderr
+    assert out.read_bytes() == blob

@@ -153,3 +153,19 @@ def test_warm_start_chain_vs_golden(orc, golden_r3, name):
         prof = r["profile"]
         assert r["record"] == golden_r3[f"chain/{name}/{f}/record"].tobytes(), (name, f)
         assert np.array_equal(prof, golden_r3[f"chain/{name}/{f}/profile"])
+
+
+@pytest.mark.parametrize("name", list(__import__("golden_cases").wide_cases().keys()))
+def test_wide_material_records_vs_golden(orc, golden_r4, name):
+    """24-bit material (--sparse-pcm=0): the oracle's records, profiles and search costs equal the genuine reference's."""
+    from golden_cases import wide_cases
+    raw = golden_r4[f"wide/{name}/raw"]
+    cfg = wide_cases()[name][1]
+    assert np.array_equal(raw, wide_cases()[name][0])
+    r = orc.encode_frame(raw, cfg, FRAMESIZE, trace=True)
+    assert r["record"] == golden_r4[f"wide/{name}/record"].tobytes()
+    assert np.array_equal(r["profile"], golden_r4[f"wide/{name}/profile"])
+    if cfg.optimize:
+        assert np.array_equal(r["trace_cost"][: cfg.maxnfunc], golden_r4[f"wide/{name}/trace_cost"][: cfg.maxnfunc])
+    dec, _ = orc.decode_frame(r["record"], raw.shape[0], FRAMESIZE)
+    assert np.array_equal(dec, raw)
