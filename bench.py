@@ -180,12 +180,28 @@ def cpu_baseline(frame, framesize, nthreads, mode="high"):
     dt = time.time() - t
     nsamp = frame.size
     secs = frame.shape[1] / RATE
+    # the same encode with the reference's own threading for --opt-cfg=dds,N: the N candidates of a generation on N threads
+    # (genuine Opt::eval_points_mt, opt/opt.cpp:11-43); only with the genuine-reference checker
+    tn = None
+    if kind == "reference" and nthreads > 1 and hasattr(chk.lib, "ref_set_parallel_eval"):
+        chk.lib.ref_set_parallel_eval(1)
+        t = time.time()
+        rn = chk.encode_frame(frame, cfg, framesize)
+        dtn = time.time() - t
+        chk.lib.ref_set_parallel_eval(0)
+        tn = {"value": nsamp / dtn / 1e6, "unit": "MSamples/s", "cores": nthreads, "seconds": dtn, "same_record": rn["record"] == r["record"],
+              "sample": f"the same frame, the {nthreads} candidates of each DDS generation on {nthreads} threads as the reference runs --opt-cfg=dds,{nthreads}"}
+    global _CPU_THREADS_N
+    _CPU_THREADS_N = tn
     return {"value": nsamp / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": kind, "seconds": dt,
             "bps": 8 * len(r["record"]) / nsamp,
             "sample": f"frame 0 of this run's batch ({secs:g} s stereo 44.1 kHz/16-bit, {nsamp} samples), --{mode} "
                       f"--opt-cfg=dds,{nthreads} --opt-reset; "
                       + ("genuine reference objects (oracle/_ref), candidates evaluated serially on 1 core"
                          if kind == "reference" else "oracle restatement, 1 core")}, r["record"]
+
+
+_CPU_THREADS_N = None
 
 
 def _cpu_encode_one(args):
@@ -475,7 +491,7 @@ def main():
         if cb is not None:
             if cb_all is not None:
                 cb["all_cores"] = cb_all
-            cb["threads8"] = None    # the CPU driver evaluates the N candidates of a generation serially (oracle/ref_driver.cpp); see all_cores
+            cb["threads8"] = _CPU_THREADS_N    # (key name kept; "cores" inside says how many threads: --dds-n)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
             out["cpu_baseline"]["same_record_as_gpu"] = bool(last_recs and last_recs[0] == cb_record)

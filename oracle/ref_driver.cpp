@@ -40,6 +40,7 @@
 #include "opt/cma.h"
 #include "common/math.h"
 #include <memory>
+#include <atomic>
 #include <span>
 #include <tuple>
 
@@ -54,6 +55,8 @@ struct OptProbe : public Opt {
 
 // RESTATED from opt/dds.cpp:12-119 (that file needs <format>); uses the genuine Opt base
 // (Random, gen_norm, reflect) and the genuine SSC0/SSC1.
+bool g_parallel_eval = false;   // ref_set_parallel_eval: candidates of a DDS generation on their own threads, as the reference runs them
+
 struct DriverDDS : public Opt {
   OptDDS::DDSCfg cfg;
   std::vector<double> *trace_cost = nullptr;
@@ -104,8 +107,10 @@ struct DriverDDS : public Opt {
         x_gen[i].second = generate_candidate(xb.second, nfunc, sigma);
         nfunc++;
       }
-      // evaluation order does not matter for the result (pure function); serial here
-      for (int i = 0; i < nthreads; i++) x_gen[i].first = eval(func, x_gen[i].second);
+      // evaluation order does not matter for the result (pure function): serial by default (traces), or -- for timing the
+      // reference's own threading -- the genuine Opt::eval_points_mt (one std::async per candidate, opt/opt.cpp:11-43)
+      if (g_parallel_eval) eval_points_mt(func, std::span<ppoint>(x_gen));
+      else for (int i = 0; i < nthreads; i++) x_gen[i].first = eval(func, x_gen[i].second);
       ppoint xb_old = xb;
       int nsucc = 0;
       for (const auto &xg : x_gen)
@@ -612,6 +617,8 @@ API double ref_search_quadratic(int search, int ndim, const double *xmin, const 
   return ret.first;
 }
 API void ref_set_search_method(int search) { g_search_method = search; }
+// 1: --opt-cfg=dds,N evaluates the N candidates of a generation on N threads (Opt::eval_points_mt); no traces in that mode
+API void ref_set_parallel_eval(int on) { g_parallel_eval = on != 0; }
 
 // ---------------------------------------------------------------- whole-frame encode/decode
 struct ref_frame_cfg {
@@ -690,14 +697,14 @@ API int ref_encode_frame(int nch, int framesize, int n, const int32_t *raw,
       pb[i].xmax = profile.coefs[lp[i]].vmax;
       xstart[i] = profile.coefs[lp[i]].vdef;
     }
-    int neval = 0;
+    std::atomic<int> neval{0};
     auto cost_func = [&](const vec1D &x) {
       FrameCoder::tch_samples tmp_error(nch, std::vector<int32_t>(samples_to_optimize));
       SacProfile tmp_profile = profile;
       for (int i = 0; i < ndim; i++) tmp_profile.coefs[lp[i]].vdef = x[i];
       fc.PredictFrame(tmp_profile, tmp_error, start_pos, samples_to_optimize, true);
       double c = fc.GetCost(CostFunc, tmp_error, samples_to_optimize);
-      if (neval < rc->maxnfunc + 32) {   // + 32: DE evaluates its whole start-up population (30 points) even when maxnfunc is smaller
+      if (!g_parallel_eval && neval < rc->maxnfunc + 32) {   // + 32: DE evaluates its whole start-up population (30 points) even when maxnfunc is smaller
         if (trace_cost) trace_cost[neval] = c;
         if (trace_coefs)
           for (int i = 0; i < 58; i++) trace_coefs[(size_t)neval * 58 + i] = tmp_profile.coefs[i].vdef;
