@@ -450,11 +450,13 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // class lists, heaviest first.  Cascade items are additionally split by how long their OLS class
   // runs (group 0: one-wave classes <= 32 taps, group 1: the panel classes): a cascade launch only
   // waits for the OLS classes of its own group, so cascade work starts under the OLS tail.
-  // The final pass (one evaluation, latency-bound: a frame's OLS class decides when its p_lpc stream is complete, 9 s for
-  // 16 taps to 40 s for 56..64 taps on a 20-s frame) groups by OLS class instead, so that the cascade of a frame starts when
-  // ITS OLS kernel has ended and the last cascade launch holds only the frames of the slowest class.
+  // SACAMD_FINAL_GROUPS=1 (experiment, off by default): the final pass groups by OLS class instead, so that the cascade of a
+  // frame may start when ITS OLS kernel has ended.  Measured on 384 x 20 s: 178.0 instead of 162.1 s per step -- the panel OLS
+  // workgroups of the slow classes fill the CUs' LDS (3 x ~50 KB), the early cascade workgroups only become resident as those
+  // drain (29 s for a launch that takes 5 s on a free chip), and the 26 small launches then serialise on the four cascade
+  // streams (profiles/r03/README.md).
   constexpr int kFastOls = 3;                       // search: OLS classes [0, kFastOls) form group 0
-  static const bool fine_groups = [] { const char *e = std::getenv("SACAMD_FINAL_GROUPS"); return !(e && e[0] == '0'); }();
+  static const bool fine_groups = [] { const char *e = std::getenv("SACAMD_FINAL_GROUPS"); return e && e[0] == '1'; }();
   const int ngroups = (want_pred && fine_groups) ? kNumOlsClasses : 2;
   auto group_of_class = [&](int ols_class) { return ngroups == 2 ? (ols_class >= kFastOls ? 1 : 0) : ols_class; };
   std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][kNumOlsClasses];
