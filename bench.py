@@ -324,15 +324,21 @@ def main():
     if dist is not None:
         gather_kind = "torch.distributed"
         if args.gather == "rccl":
-            try:
-                idt = torch.zeros(api.COMM_ID_BYTES, dtype=torch.uint8, device=device)
-                if rank == 0:
+            idt = torch.zeros(api.COMM_ID_BYTES, dtype=torch.uint8, device=device)
+            if rank == 0:
+                try:
                     idt = torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8).to(device)
-                dist.broadcast(idt, 0)
-                comm = api.Comm(local_rank, rank, world, bytes(idt.cpu().numpy().tobytes()))
+                except Exception as e:   # an all-zero id tells every rank that there is none
+                    gather_note = f"sacamd_comm_unique_id failed: {e}"
+            dist.broadcast(idt, 0)
+            uid = bytes(idt.cpu().numpy().tobytes())
+            try:
+                if not any(uid):
+                    raise RuntimeError("no RCCL unique id from rank 0")
+                comm = api.Comm(local_rank, rank, world, uid)
                 ok = torch.tensor([1], dtype=torch.int32, device=device)
             except Exception as e:       # reported in the line; the run goes on with the torch.distributed gather
-                gather_note = f"sacamd_comm_create failed on rank {rank}: {e}"
+                gather_note = gather_note or f"sacamd_comm_create failed on rank {rank}: {e}"
                 ok = torch.tensor([0], dtype=torch.int32, device=device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks use the same gather
             if int(ok.item()) == 1:
@@ -345,7 +351,7 @@ def main():
 
     def gather(recs):
         if comm is not None:
-            return comm.gather_records(my_ids, recs, total_frames)
+            return comm.gather_records(my_ids, recs, total_frames, as_bytes=False)
         out = gather_records(recs, rank, world, device)       # rank-major order
         if out is None or args.scaling != "strong":
             return out

@@ -152,11 +152,13 @@ def _default_cap(recs, total_frames):
     return total_frames * (2 * longest + (1 << 16)) if longest else max(64, total_frames) * (4 << 20)
 
 
-def _unpack_gathered(rc, out, out_off, total_frames, rank, err):
+def _unpack_gathered(rc, out, out_off, total_frames, rank, err, as_bytes=True):
     if rc != 0:
         raise SacAmdError(f"record gather failed ({rc}): {err()}")
     if rank != 0:
         return None
+    if not as_bytes:       # views into the receive buffer (no copy of a multi-gigabyte job's records)
+        return [out[out_off[f]: out_off[f + 1]] for f in range(total_frames)]
     return [out[out_off[f]: out_off[f + 1]].tobytes() for f in range(total_frames)]
 
 
@@ -191,9 +193,10 @@ class Comm:
             self.lib.sacamd_comm_destroy(self.h)
             self.h = None
 
-    def gather_records(self, frame_ids, recs, total_frames: int, cap: int = None):
+    def gather_records(self, frame_ids, recs, total_frames: int, cap: int = None, as_bytes: bool = True):
         """Collective.  recs: this rank's frame records, frame_ids their global frame numbers.  Rank 0 returns the list of
-        all total_frames records in frame order (what WriteEncoded appends to the file), other ranks None."""
+        all total_frames records in frame order (what WriteEncoded appends to the file; bytes, or uint8 array views of the
+        receive buffer with as_bytes=False), other ranks None."""
         ids, off, blob = _pack_records(frame_ids, recs)
         if self.rank == 0:
             cap = int(cap) if cap is not None else _default_cap(recs, total_frames)
@@ -202,7 +205,7 @@ class Comm:
             cap, out, out_off = 0, None, None
         rc = self.lib.sacamd_gather_records(self.h, len(recs), _vp(ids), _vp(blob), _vp(off), int(total_frames), _vp(out),
                                             c_longlong(cap), _vp(out_off))
-        return _unpack_gathered(rc, out, out_off, total_frames, self.rank, lambda: self.lib.sacamd_comm_last_error(self.h).decode())
+        return _unpack_gathered(rc, out, out_off, total_frames, self.rank, lambda: self.lib.sacamd_comm_last_error(self.h).decode(), as_bytes)
 
 
 def gather_records_via(transport: TransportC, frame_ids, recs, total_frames: int, cap: int = None):
