@@ -707,3 +707,23 @@ def test_24bit_subframe_plan_and_wav_roundtrip(api, orc, tmp_path):
     r = subprocess.run([exe, "--decode", str(sac), str(out)], capture_output=True, text=True)
     assert r.returncode == 0 and "Audio MD5: ok" in r.stdout, r.stdout + r.stderr
     assert out.read_bytes() == blob
+
+
+def test_gpu_decoder_groups_frames_by_ring_size(api):
+    """Frames whose profiles are long in DIFFERENT cascade stages: the history rings of a decoder launch are sized for the
+    per-stage maximum over its frames, which must fit one CU's LDS -- such frames go into separate launches (round 3 fix:
+    `sacenc --decode` of a DDS-searched file failed with "history rings of a frame group exceed the LDS")."""
+    P = api.default_profile()
+    raws = [synth_pcm(2500, 2, 900 + i, RATE) for i in range(3)]
+    profs = np.stack([P[:, 2].copy() for _ in raws])
+    profs[0][[28, 31]] = 8192                                  # stage 0 at the box maximum, both channels
+    profs[1][[28, 31]] = 256
+    profs[1][[29, 32]] = 4096; profs[1][[30, 33]] = 2048; profs[1][[37, 38]] = 1024     # stages 1..3 at their maxima
+    ctx = api.Context(2, FRAMESIZE, len(raws))
+    ctx.upload_i32(raws, FRAMESIZE)
+    recs, _ = ctx.encode_frames(api.make_cfg("normal"), profiles=profs)
+    pcm, prof = ctx.decode_frames(recs, FRAMESIZE)
+    ctx.close()
+    assert np.array_equal(prof, profs)
+    for f, raw in enumerate(raws):
+        assert np.array_equal(pcm[f], raw), f
