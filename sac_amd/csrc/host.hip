@@ -545,9 +545,37 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, hipEventRecord(c->ev_join[kMark], side[kMark]));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[kMark], 0));
   bool lms_used[sacamd_ctx::kSide] = {};
+  // Stream of every cascade launch.  Launches on one stream run one after the other, and a cascade launch is as long as its
+  // slowest item whatever its size, so the launches that become ready together should sit on different streams, the longest
+  // first.  Search (two groups): group 0 (items whose OLS class is one of the fast ones) takes the four cascade streams and
+  // the streams of the fast OLS classes -- those kernels are exactly what the group waits for anyway; group 1 takes the
+  // streams of the slow OLS classes.  Within a group the whole-CU layout (class 2: its workgroups need a drained CU) goes
+  // first, then the launches by descending work.  SACAMD_LMS_STREAMS=0 restores the round-robin over four streams.
+  static const bool spread = [] { const char *e = std::getenv("SACAMD_LMS_STREAMS"); return !(e && e[0] == '0'); }();
+  std::vector<int> lms_stream(lms_launches.size());
+  std::vector<size_t> lms_order(lms_launches.size());
+  std::iota(lms_order.begin(), lms_order.end(), (size_t)0);
+  if (spread && ngroups == 2) {
+    std::vector<double> work(lms_launches.size(), 0.0);
+    for (size_t q = 0; q < lms_launches.size(); q++) {
+      const LmsLaunch &ll = lms_launches[q];
+      for (int i = 0; i < ll.count; i++) if (flat[ll.first + i] >= 0) work[q] += (double)taps(flat[ll.first + i]);
+      if (ll.cls == 2) work[q] = 1e300;
+    }
+    std::stable_sort(lms_order.begin(), lms_order.end(), [&](size_t a, size_t b) {
+      return lms_launches[a].group != lms_launches[b].group ? lms_launches[a].group < lms_launches[b].group : work[a] > work[b]; });
+    std::vector<int> pool[2];
+    for (int k = kNumOlsClasses; k < kMark; k++) pool[0].push_back(k);
+    for (int k = 0; k < kFastOls; k++) pool[0].push_back(k);
+    for (int k = kFastOls; k < kNumOlsClasses; k++) pool[1].push_back(k);
+    size_t used[2] = {0, 0};
+    for (size_t q : lms_order) { const int g = lms_launches[q].group; lms_stream[q] = pool[g][used[g]++ % pool[g].size()]; }
+  } else {
+    for (size_t q = 0; q < lms_launches.size(); q++) lms_stream[q] = kNumOlsClasses + (int)(q % kLmsStreams);
+  }
   auto launch_one = [&](size_t q) -> int {
     const LmsLaunch &ll = lms_launches[q];
-    const int si = kNumOlsClasses + (int)(q % kLmsStreams);
+    const int si = lms_stream[q];
     hipStream_t st = side[si];
     if (!lms_used[si]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); lms_used[si] = true; }
     for (int k = 0; k < kNumOlsClasses; k++)
@@ -557,8 +585,8 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     launch_lms(st, c->d_items.p, c->d_idx.p + ll.first, ll.count, ll.cls, ll.rc, pv, c->d_tab.p, c->d_p.p, c->d_q.p);
     return 0;
   };
-  for (size_t q = 0; q < lms_launches.size(); q++) { int r = launch_one(q); if (r) return r; }
-  for (int si = kNumOlsClasses; si < kMark; si++)
+  for (size_t q : lms_order) { int r = launch_one(q); if (r) return r; }
+  for (int si = 0; si < kMark; si++)
     if (lms_used[si]) { HIPCHK(c, hipEventRecord(c->ev_join[si], side[si])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[si], 0)); }
   HIPCHK(c, hipEventRecord(sp_lms.b, c->stream));
   sp_lms.a = sp_ols.b;                               // cascade span = what is left after the last OLS kernel ended
