@@ -7,6 +7,12 @@
 //                                           all frame records of the file decoded as one batch (sacamd_decode_frames),
 //                                           MD5 of the sample bytes checked against the header's
 //
+//   sacenc ... --world=W --rank=R --comm-id=FILE [--device=D] in.wav ... out        one process per GPU (the C++ host side of
+//                                           the multi-GPU path): every rank plans the same frame list, sacamd_assign_frames
+//                                           splits it by cost, each rank encodes its share on its GPU, sacamd_gather_records
+//                                           (RCCL) brings the records to rank 0 in frame order, rank 0 writes the files.  FILE
+//                                           carries the RCCL unique id from rank 0 to the others (any shared path).
+//
 // The encode side of the reference's command line (/root/reference/src/cmdline.cpp:127-235) and of
 // Codec::EncodeFile (libsac/libsac.cpp:782-855): reads of framelen seconds, adaptive sub-frame split
 // (sacamd_plan_subframes), every frame of every input file staged as ONE batch per max-frames
@@ -22,6 +28,7 @@
 #include <iostream>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/sac_amd.h"
 #include "sacfile.h"
@@ -43,6 +50,9 @@ int main(int argc, char **argv) {
     int framelen = 20, adapt_block = 1, max_frames = 256;
     int list_mode = 0;             // 1: --list, 2: --listfull (host only)
     bool decode_mode = false;      // --decode
+    int world = 1, rank = 0, device = -1;   // --world / --rank / --device: one process per GPU
+    std::string comm_id_file;
+    bool force_gather = false;     // --force-gather: take the communicator / gather path with one rank too (one-GPU test)
     bool header_only = false;      // --header-only: write header + MD5 of each input and stop (no device needed; tests)
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
@@ -75,6 +85,11 @@ int main(int argc, char **argv) {
       else if (a == "--list") list_mode = 1;
       else if (a == "--listfull") list_mode = 2;
       else if (a == "--decode") decode_mode = true;
+      else if (a.rfind("--world=", 0) == 0) world = std::atoi(a.c_str() + 8);
+      else if (a.rfind("--rank=", 0) == 0) rank = std::atoi(a.c_str() + 7);
+      else if (a.rfind("--device=", 0) == 0) device = std::atoi(a.c_str() + 9);
+      else if (a.rfind("--comm-id=", 0) == 0) comm_id_file = a.substr(10);
+      else if (a == "--force-gather") force_gather = true;
       else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
       else pos.push_back(a);
     }
@@ -166,9 +181,30 @@ int main(int argc, char **argv) {
       return 0;
     }
 
+    const bool use_comm = world > 1 || force_gather;
+    if (world < 1 || rank < 0 || rank >= world || (use_comm && comm_id_file.empty())) { std::cerr << "sacenc: --world=W --rank=R (0 <= R < W) --comm-id=FILE\n"; return 2; }
+    if (device < 0) device = rank;                     // one process per GPU: rank r drives GPU r unless told otherwise
+    if (use_comm && !cfg.reset) throw std::runtime_error("frames are sharded across ranks: --opt-reset semantics only");
     sacamd_ctx *ctx = nullptr;
-    if (sacamd_ctx_create(0, nch, maxfs, max_frames, &ctx) != 0) throw std::runtime_error("no usable gfx950 device (sacamd_ctx_create failed)");
+    if (sacamd_ctx_create(device, nch, maxfs, max_frames, &ctx) != 0) throw std::runtime_error("no usable gfx950 device (sacamd_ctx_create failed)");
     auto chk = [&](int rc) { if (rc != 0) throw std::runtime_error(std::string("sac_amd: ") + sacamd_last_error(ctx)); };
+    sacamd_comm *comm = nullptr;
+    if (use_comm) {                                    // RCCL communicator; the unique id travels through the file
+      uint8_t id[SACAMD_COMM_ID_BYTES];
+      if (rank == 0) {
+        if (sacamd_comm_unique_id(id) != 0) throw std::runtime_error("sacamd_comm_unique_id failed");
+        { std::ofstream o(comm_id_file + ".tmp", std::ios::binary); o.write((const char *)id, sizeof(id)); }
+        if (std::rename((comm_id_file + ".tmp").c_str(), comm_id_file.c_str()) != 0) throw std::runtime_error("cannot write " + comm_id_file);
+      } else {
+        bool got = false;
+        for (int tries = 0; tries < 6000 && !got; tries++) {             // up to 10 minutes
+          std::ifstream f(comm_id_file, std::ios::binary);
+          if (f && f.read((char *)id, sizeof(id))) got = true; else usleep(100000);
+        }
+        if (!got) throw std::runtime_error("no RCCL unique id in " + comm_id_file);
+      }
+      if (sacamd_comm_create(device, rank, world, id, &comm) != 0) throw std::runtime_error("sacamd_comm_create failed");
+    }
 
     // frame list: reads of maxfs samples, each cut into sub-frames (libsac.cpp:805-820)
     std::vector<FrameRef> frames;
@@ -184,9 +220,28 @@ int main(int argc, char **argv) {
       }
     }
 
+    // multi-GPU: this rank's share of the frame list (longest first by estimated cost channels * (E * T_opt + T));
+    // every rank computes the same assignment
+    const std::vector<FrameRef> all_frames = frames;
+    std::vector<int> my_ids(all_frames.size());
+    for (size_t i = 0; i < all_frames.size(); i++) my_ids[i] = (int)i;
+    if (use_comm) {
+      std::vector<double> cost(all_frames.size());
+      std::vector<int> owner(all_frames.size());
+      for (size_t i = 0; i < all_frames.size(); i++) {
+        const double T = all_frames[i].length, Topt = std::min(T, std::ceil(maxfs * cfg.fraction));
+        cost[i] = nch * ((cfg.optimize ? cfg.maxnfunc : 0) * Topt + T);
+      }
+      chk(sacamd_assign_frames(cost.data(), (int)cost.size(), world, owner.data()));
+      frames.clear(); my_ids.clear();
+      for (size_t i = 0; i < all_frames.size(); i++) if (owner[i] == rank) { frames.push_back(all_frames[i]); my_ids.push_back((int)i); }
+    }
+
     // encode in batches of max_frames
     std::vector<std::vector<uint8_t>> payload(wavs.size());
     std::vector<int> nfr(wavs.size(), 0);
+    std::vector<uint8_t> my_recs;                    // multi-GPU: this rank's records back to back, my_off[i]..my_off[i+1]
+    std::vector<long long> my_off(1, 0);
     for (size_t b0 = 0; b0 < frames.size(); b0 += (size_t)max_frames) {
       const int nb = (int)std::min((size_t)max_frames, frames.size() - b0);
       int stride = 0;
@@ -209,12 +264,32 @@ int main(int argc, char **argv) {
       std::vector<long long> off(nb + 1);
       chk(sacamd_encode_frames(ctx, &cfg, prof.data(), out.data(), cap, off.data()));
       for (int i = 0; i < nb; i++) {
+        if (use_comm) { my_recs.insert(my_recs.end(), out.begin() + off[i], out.begin() + off[i + 1]); my_off.push_back((long long)my_recs.size()); continue; }
         auto &dst = payload[frames[b0 + i].file];
         dst.insert(dst.end(), out.begin() + off[i], out.begin() + off[i + 1]);
         nfr[frames[b0 + i].file]++;
       }
     }
     sacamd_ctx_destroy(ctx);
+    if (use_comm) {
+      // the one exchange of the path: all records to rank 0 in frame order (== the order WriteEncoded appends them)
+      const int total = (int)all_frames.size();
+      long long cap = 0;
+      for (auto &fr : all_frames) cap += (long long)fr.length * nch * 4 + 2 * 4096 + 70000;
+      std::vector<uint8_t> all(rank == 0 ? (size_t)cap : 0);
+      std::vector<long long> all_off(rank == 0 ? (size_t)total + 1 : 0);
+      if (my_recs.empty()) my_recs.push_back(0);
+      const int rc = sacamd_gather_records(comm, (int)my_ids.size(), my_ids.data(), my_recs.data(), my_off.data(), total,
+                                           rank == 0 ? all.data() : nullptr, rank == 0 ? cap : 0, rank == 0 ? all_off.data() : nullptr);
+      if (rc != 0) throw std::runtime_error(std::string("sacamd_gather_records: ") + sacamd_comm_last_error(comm));
+      sacamd_comm_destroy(comm);
+      if (rank != 0) return 0;
+      for (int i = 0; i < total; i++) {
+        auto &dst = payload[all_frames[i].file];
+        dst.insert(dst.end(), all.begin() + all_off[i], all.begin() + all_off[i + 1]);
+        nfr[all_frames[i].file]++;
+      }
+    }
 
     for (size_t f = 0; f < wavs.size(); f++) {
       std::string op = outarg;

@@ -405,6 +405,13 @@ def test_sacenc_cli_matches_python_driver(api, tmp_path):
         want = tmp_path / f"py{i}.sac"
         C.write_sac(str(want), info, maxlen, recs)
         assert (outdir / f"in{i}.sac").read_bytes() == want.read_bytes()
+    # the multi-GPU host path of the same program on this box's one GPU: communicator from an id file, cost-based frame
+    # assignment, sacamd_gather_records (RCCL, one rank), rank 0 writes the files -- same bytes
+    out2 = tmp_path / "out2"; out2.mkdir()
+    subprocess.run([exe, "--high", "--opt-cfg=dds,4", f"--framelen={maxlen}", "--world=1", "--rank=0", f"--comm-id={tmp_path / 'id.bin'}",
+                    "--force-gather", *names, str(out2)], check=True)
+    for i in range(len(blobs)):
+        assert (out2 / f"in{i}.sac").read_bytes() == (outdir / f"in{i}.sac").read_bytes()
 
 
 def test_search_memo_is_exact(api, orc):
