@@ -353,7 +353,9 @@ def main():
 
     def gather(recs):
         if comm is not None:
-            return comm.gather_records(my_ids, recs, total_frames, as_bytes=False)
+            nb = torch.tensor([sum(len(r) for r in recs)], dtype=torch.int64, device=device)
+            dist.all_reduce(nb)                            # rank 0's receive buffer gets the job's exact size
+            return comm.gather_records(my_ids, recs, total_frames, cap=int(nb.item()) + 4096, as_bytes=False)
         out = gather_records(recs, rank, world, device)       # rank-major order
         if out is None or args.scaling != "strong":
             return out
