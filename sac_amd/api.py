@@ -193,6 +193,12 @@ class Comm:
             self.lib.sacamd_comm_destroy(self.h)
             self.h = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def gather_records(self, frame_ids, recs, total_frames: int, cap: int = None, as_bytes: bool = True):
         """Collective.  recs: this rank's frame records, frame_ids their global frame numbers.  Rank 0 returns the list of
         all total_frames records in frame order (what WriteEncoded appends to the file; bytes, or uint8 array views of the

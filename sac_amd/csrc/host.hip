@@ -677,6 +677,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   for (int k = 0; k < sacamd_ctx::kSide; k++) if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
   for (int k = 0; k < kNumOlsClasses; k++) if (c->ev_ols[k]) (void)hipEventDestroy(c->ev_ols[k]);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_epoch) (void)hipEventDestroy(c->ev_epoch);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
   c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
