@@ -212,13 +212,15 @@ def _cpu_encode_one(args):
     return len(r["record"])
 
 
-def cpu_baseline_all_cores(frames, framesize, nthreads, mode, max_procs=int(os.environ.get("SAC_BENCH_ALLCORES_PROCS", 128))):
-    """The same CPU encode on all host cores: P frames of this run's batch in P processes (one frame per core, the way the
-    reference's own README timings run files in parallel).  P = half the hardware threads the process may use (the physical
-    cores of an SMT-2 host), at most 128 and at most the batch.  Returns MSamples/s, the core count used and the wall time."""
+def cpu_baseline_all_cores(frames, framesize, nthreads, mode, max_procs=int(os.environ.get("SAC_BENCH_ALLCORES_PROCS", 32))):
+    """The same CPU encode on many host cores at once: P frames of this run's batch in P processes (one frame per core, the
+    way the reference's own README timings run files in parallel).  P = 32: on the GPU boxes of this pool the aggregate rate
+    does not grow beyond that (they show 256 hardware threads, but 32 processes already run at a third of the one-process
+    rate each, 0.44 MSamples/s together, and 128 processes reach 0.34 MSamples/s in 671 s -- profiles/r03/README.md).
+    Returns MSamples/s, the process count and the wall time."""
     import multiprocessing as mp
     cores = len(os.sched_getaffinity(0))
-    procs = max(1, min(max(cores // 2, 1) if cores > 8 else cores, max_procs, len(frames)))
+    procs = max(1, min(cores, max_procs, len(frames)))
     jobs = [(frames[i], framesize, nthreads, mode) for i in range(procs)]
     t = time.time()
     with mp.get_context("fork").Pool(procs) as pool:
