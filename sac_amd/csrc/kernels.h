@@ -39,6 +39,10 @@ void launch_dec_cascade(hipStream_t s, const WorkItem *d_items, const int *d_idx
                         const double *d_tab, const double *d_p, double *d_q, const DecLink *d_links, int *d_started /*host-visible*/);
 void launch_dec_olsbias(hipStream_t s, const WorkItem *d_items, const int *d_idx, int n_ols, int n_bias, bool any_wide, PcmView v, double *d_p, const double *d_q,
                         const FrameStatsD *d_stats, int nch, const DecLink *d_lk_ols, const DecLink *d_lk_bias);
+// the same group as ONE launch (3 m blocks, one CU each): co-residency by construction, no concurrent queues needed
+void launch_dec_all(hipStream_t s, const WorkItem *d_items, const int *d_idx, int m, size_t lds_cascade, bool any_wide, LmsRingCap rc, PcmView v,
+                    const double *d_tab, double *d_p, double *d_q, const FrameStatsD *d_stats, int nch, const DecLink *d_lk_lms, const DecLink *d_lk_ols,
+                    const DecLink *d_lk_bias);
 void launch_used_prefix(hipStream_t s, int count, const unsigned char *d_used, const long long *d_off_used, int *d_prefix);
 // ---- costs / s2u (kernels_misc.hip)
 void launch_cost(hipStream_t s, int kind, const int *d_err, const long long *d_off, const int *d_n, int count,

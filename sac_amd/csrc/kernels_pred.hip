@@ -1,5 +1,6 @@
 // sac_amd/csrc/kernels_pred.hip -- gfx950 kernels of the three predictor stages.
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fma only; see canon.h).
+#include <algorithm>
 #include "kernels.h"
 #include "pred_bias.h"
 #include "pred_lms.h"
@@ -366,6 +367,52 @@ void launch_dec_olsbias(hipStream_t s, const WorkItem *d_items, const int *d_idx
   if (ensure_dyn_lds((const void *)k_dec_olsbias, ols_panel2_lds_bytes(96), done) != hipSuccess) return;
   const size_t bytes = any_wide ? ols_panel2_lds_bytes(96) : OlsLdsFast::bytes(64);
   hipLaunchKernelGGL(k_dec_olsbias, dim3(n_ols + n_bias), dim3(kDecThreads), bytes, s, d_items, d_idx, n_ols, v, d_p, d_q, d_stats, nch, d_lk_ols, d_lk_bias);
+}
+
+// One-launch form of the same group: blocks [0, m) cascade, [m, 2m) OLS, [2m, 3m) bias of the items idx[b].  Every block is
+// compiled for the cascade's register budget and asks for the largest LDS of the three roles, so each takes a CU of its own
+// (3 m <= the CUs of the chip: the host sizes the group) -- and since all blocks of ONE grid that fits the chip are resident
+// together, the stages can wait for each other without any assumption about concurrent hardware queues.
+__global__ __launch_bounds__(kDecThreads, 1) void k_dec_all(const WorkItem *items, const int *idx, int m, PcmView v, const double *tab, double *pbuf, double *qbuf,
+                                                             const FrameStatsD *stats, int nch, LmsRingCap rc, const DecLink *lk_lms, const DecLink *lk_ols,
+                                                             const DecLink *lk_bias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = (int)blockIdx.x;
+  const int ii = idx[b];
+  const WorkItem &it = items[ii];
+  const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+  if (b < m) {
+    switch (it.lms_class) {
+      case 10: dec_cascade_role<10>(it, self, tab, pbuf, qbuf, smem, rc, lk_lms + ii); break;
+      case 11: dec_cascade_role<11>(it, self, tab, pbuf, qbuf, smem, rc, lk_lms + ii); break;
+      case 12: dec_cascade_role<12>(it, self, tab, pbuf, qbuf, smem, rc, lk_lms + ii); break;
+      default: dec_cascade_role<9>(it, self, tab, pbuf, qbuf, smem, rc, lk_lms + ii); break;
+    }
+  } else if (b < 2 * m) {
+    const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
+    if (it.p.n_ols <= 64) {
+      if (threadIdx.x >= 64) return;
+      ExecDev<64> ex;
+      ols_stage_reg<ExecDev<64>, 64>(ex, it.p, self, other, it.n, pbuf + it.off_pin, smem, nullptr, lk_ols + ii);
+    } else {
+      ExecDev<256> ex;
+      ols_stage_panel2<ExecDev<256>, 96>(ex, it.p, self, other, it.n, pbuf + it.off_pin, smem, nullptr, lk_ols + ii);
+    }
+  } else {
+    if (threadIdx.x != 0) return;
+    const int mean = stats[it.frame * nch + it.ch_self].mean;
+    bias_stage(it.p, nullptr, it.n, qbuf + it.off_p, mean, nullptr, nullptr, reinterpret_cast<double *>(smem), nullptr, lk_bias + ii);
+  }
+}
+void launch_dec_all(hipStream_t s, const WorkItem *d_items, const int *d_idx, int m, size_t lds_cascade, bool any_wide, LmsRingCap rc, PcmView v,
+                    const double *d_tab, double *d_p, double *d_q, const FrameStatsD *d_stats, int nch, const DecLink *d_lk_lms, const DecLink *d_lk_ols,
+                    const DecLink *d_lk_bias) {
+  if (m <= 0) return;
+  static std::atomic<unsigned long long> done{0};
+  if (ensure_dyn_lds((const void *)k_dec_all, 160 * 1024, done) != hipSuccess) return;
+  // at least 81 KB: no two blocks on one CU, whatever their roles need
+  const size_t bytes = std::max({lds_cascade, any_wide ? ols_panel2_lds_bytes(96) : OlsLdsFast::bytes(64), (size_t)81 * 1024});
+  hipLaunchKernelGGL(k_dec_all, dim3(3 * m), dim3(kDecThreads), bytes, s, d_items, d_idx, m, v, d_tab, d_p, d_q, d_stats, nch, rc, d_lk_lms, d_lk_ols, d_lk_bias);
 }
 
 // prefix[j] = number of used values in [-32768, -32768 + j - 1], j = 0 .. 65537 (Remap::isUsed: 0 is always used), one block per job
