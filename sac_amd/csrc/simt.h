@@ -71,16 +71,19 @@ struct DecLink {
   const int *merr;           // bias stage: the entropy-decoded (mapped) residuals
   const int *prefix;         // bias stage, mapped streams: prefix[j] = number of used values in [-32768, -32768 + j - 1]; else null
 };
-// true when *p >= need; false when the link has failed (never blocks for more than ~2 s)
+// true when *p >= need; false when the link has failed.  The wait is bounded by a number of polls (about a microsecond each:
+// s_sleep + two L2 round trips -> a few seconds), NOT by s_memtime differences: when the device's hardware queues are
+// oversubscribed (a second process with its own queues on the same GPU) waves are saved and restored by the queue scheduler,
+// and a wave restored elsewhere read a time base that made `now - t0` jump past any bound -- every wait "timed out" at once
+// and the decoder failed beside an idle HIP process although it ran alone (profiles/r03/README.md).
 SA_HD bool sa_wait_ge(const int *p, int need, int *fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  while (true) {
+  for (unsigned polls = 0;; polls++) {
     __builtin_amdgcn_s_sleep(8);
     if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
     if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    if (__builtin_readcyclecounter() - t0 > 5000000000ull) { __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    if (polls > 4000000u) { __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
   }
 #else
   (void)fail;
