@@ -10,12 +10,17 @@
  * across the ABI; the caller owns all host buffers; the context owns all device buffers and its main
  * HIP stream; a context is single-submitter (concurrency is expressed by batching frames and
  * candidates).  Distinct contexts hold independent state and may be driven from different threads; on one
- * device they share a pool of 13 side streams (the hardware runs a limited number of queues at once) and
+ * device they share a pool of 13 side streams (the hardware runs a limited number of queues at once; a second PROCESS with its
+ * own queues on the same GPU oversubscribes them, which costs time but no longer correctness: profiles/r03/README.md) and
  * take turns with their search phases (one search saturates the chip).  There is no CPU fallback: if no
  * gfx950 device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
  *
- * Environment switches: SACAMD_TRACE=1 prints every predictor launch with its duration; SACAMD_CANON_SYSTOLIC=1 selects the
- * round-2 cascade layouts for the final pass and SACAMD_OLS_FINAL_PANEL=0 the one-wave OLS kernel for it (A/B measurements).
+ * Environment switches (read once per process).  SACAMD_TRACE=1 prints every predictor launch with its duration and start
+ * offset.  A/B measurements: SACAMD_CANON_SYSTOLIC=1 the round-2 cascade layouts for the final pass;
+ * SACAMD_OLS_FINAL_PANEL=0 the one-wave OLS kernel for it; SACAMD_LMS_STREAMS=0 cascade launches round-robin over four streams;
+ * SACAMD_FINAL_GROUPS=1 final-pass cascade launches grouped by OLS class; SACAMD_TAIL_STREAMS=1 a stream set of its own for the
+ * final pass (software-pipelined batches).  Decoder: SACAMD_DEC_SINGLE=1 every frame group as one launch (the fallback form);
+ * SACAMD_DEC_ZERO=0 skips zeroing the decoder's planes.
  */
 #ifndef SAC_AMD_H
 #define SAC_AMD_H
