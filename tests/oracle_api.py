@@ -267,6 +267,13 @@ class Checker:
 
     def decode_frame(self, rec: bytes, nch, framesize):
         buf = np.frombuffer(rec, np.uint8).copy()
+        if nch == 2 and buf.size >= 4 + 58 * 4:
+            # the reference's stereo channel loop (libsac.cpp:128-140, :166-198) never terminates when the frame is shorter
+            # than nS1 = |round(coef 27)|; the oracle restates that loop, so refuse instead of hanging the caller
+            ns = int(np.frombuffer(buf[:4].tobytes(), "<u4")[0])
+            ns1 = abs(int(np.round(np.frombuffer(buf[4: 4 + 58 * 4].tobytes(), "<f4")[27])))
+            if ns < ns1:
+                raise ValueError(f"stereo frame of {ns} samples with nS1 = {ns1}: the reference decoder does not terminate on it")
         out = np.zeros((nch, framesize), np.int32)
         coefs = np.zeros(58, np.float32)
         # out is planar [nch][n]; decode into a flat buffer then reshape
