@@ -310,7 +310,12 @@ static __device__ __forceinline__ void dec_cascade_role(const WorkItem &it, cons
   double sp[4];
   for (int s = 0; s < 4; s++) sp[s] = it.sum_powtab[s];
   ExecDev<kDecThreads> ex;
-  lms_stage<ExecDev<kDecThreads>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, it.p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_pin, qbuf + it.off_p, smem, rc.c, nullptr,
+  // every block lays out its history rings for ITS item's stage lengths (a decoder block is one work-item and owns its CU's
+  // LDS): the launch asks for the largest single footprint, not for the per-stage maximum over all its items
+  (void)rc;
+  int own[4];
+  for (int s = 0; s < 4; s++) own[s] = it.p.vn[s] + 1;
+  lms_stage<ExecDev<kDecThreads>, C, lms_canon_mode(CLS), LmsCfg<CLS>::ROUNDS>(ex, it.p, sp, tab + it.off_tab, self, it.n, pbuf + it.off_pin, qbuf + it.off_p, smem, own, nullptr,
                                                                                 link, it.off_tabc >= 0 ? tab + it.off_tabc : nullptr);
 }
 __global__ __launch_bounds__(kDecThreads, 1) void k_dec_cascade(const WorkItem *items, const int *idx, PcmView v, const double *tab, const double *pbuf, double *qbuf,

@@ -666,9 +666,9 @@ def test_decode_cli_restores_the_wav_files(api, tmp_path):
     for i, blob in enumerate((a, b)):
         src = tmp_path / f"in{i}.wav"; src.write_bytes(blob)
         sac = tmp_path / f"f{i}.sac"
-        # (--normal: the default profile.  A search over these short 8 kHz frames drives the cascade to the box maximum of
-        # 15 360 taps per channel, more than the decoder's 256-lane layouts hold in one CU's LDS -- it reports that and stops)
-        subprocess.run([exe, "--normal", f"--framelen={maxlen}", str(src), str(sac)], check=True)
+        # (a search over these short 8 kHz frames drives the cascade towards the box maximum of 15 360 taps per channel, the
+        # two channels in different stages: the decoder lays out every channel's rings on its own)
+        subprocess.run([exe, "--high", "--opt-cfg=dds,4", f"--framelen={maxlen}", str(src), str(sac)], check=True)
         out1 = tmp_path / f"cpp{i}.wav"
         r = subprocess.run([exe, "--decode", str(sac), str(out1)], capture_output=True, text=True)
         assert r.returncode == 0 and "Audio MD5: ok" in r.stdout, r.stdout + r.stderr
@@ -723,15 +723,17 @@ def test_24bit_subframe_plan_and_wav_roundtrip(api, orc, tmp_path):
 
 
 def test_gpu_decoder_groups_frames_by_ring_size(api):
-    """Frames whose profiles are long in DIFFERENT cascade stages: the history rings of a decoder launch are sized for the
-    per-stage maximum over its frames, which must fit one CU's LDS -- such frames go into separate launches (round 3 fix:
-    `sacenc --decode` of a DDS-searched file failed with "history rings of a frame group exceed the LDS")."""
+    """Frames -- and the two channels of one frame -- whose profiles are long in DIFFERENT cascade stages: every decoder
+    cascade block lays out its history rings for its own item, so the launch needs the largest single footprint and not the
+    per-stage maximum over its items (which exceeds a CU's LDS here; round 3 fix: `sacenc --decode` of a DDS-searched file
+    failed with "history rings of a frame group exceed the LDS")."""
     P = api.default_profile()
     raws = [synth_pcm(2500, 2, 900 + i, RATE) for i in range(3)]
     profs = np.stack([P[:, 2].copy() for _ in raws])
     profs[0][[28, 31]] = 8192                                  # stage 0 at the box maximum, both channels
     profs[1][[28, 31]] = 256
     profs[1][[29, 32]] = 4096; profs[1][[30, 33]] = 2048; profs[1][[37, 38]] = 1024     # stages 1..3 at their maxima
+    profs[2][28] = 8192; profs[2][31] = 256; profs[2][32] = 4096; profs[2][33] = 2048; profs[2][38] = 1024   # the two CHANNELS of one frame long in different stages
     ctx = api.Context(2, FRAMESIZE, len(raws))
     ctx.upload_i32(raws, FRAMESIZE)
     recs, _ = ctx.encode_frames(api.make_cfg("normal"), profiles=profs)
