@@ -238,6 +238,17 @@ def _verify_one(args):
     return bool(np.array_equal(dec, frame))
 
 
+def _flush_c_stdio():
+    """stdout of C / C++ code in this process (oracle/_ref prints a few lines when it is loaded) sits in the C library's
+    buffer until exit when stdout is a pipe; flush it now so that the JSON line is the LAST thing this process prints."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def self_launch(ngpus):
     """`python bench.py --gpus N` without torchrun: become `python -m torch.distributed.run ... bench.py ...`."""
     import socket
@@ -613,6 +624,7 @@ def main():
         if rank == 0:        # cumulative line (the timed region is still open: no barrier here)
             dt_now = time.perf_counter() - t0
             latest["line"] = json.dumps(build_line(nsteps, dt_now, allrecs, last_recs, final=False))
+            _flush_c_stdio()
             print(latest["line"], flush=True)
         step += 1
     barrier()
@@ -640,6 +652,7 @@ def main():
             out["verified_lossless"] = bool(all(oks))
             out["verified_frames"] = pick
             out["verified_with"] = "oracle/_ref decoder (genuine reference objects)" if ref_available() else "oracle restatement"
+        _flush_c_stdio()                       # (the reference objects print from C++ at load time: keep that ahead of the line)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
