@@ -19,7 +19,8 @@
  * offset.  A/B measurements: SACAMD_CANON_SYSTOLIC=1 the round-2 cascade layouts for the final pass;
  * SACAMD_OLS_FINAL_PANEL=0 the one-wave OLS kernel for it; SACAMD_LMS_STREAMS=0 cascade launches round-robin over four streams;
  * SACAMD_FINAL_GROUPS=1 final-pass cascade launches grouped by OLS class; SACAMD_TAIL_STREAMS=1 a stream set of its own for the
- * final pass (software-pipelined batches).  Decoder: SACAMD_DEC_SINGLE=1 every frame group as one launch (the fallback form);
+ * final pass (software-pipelined batches); SACAMD_OLS_SMALL_PANEL=N the panel OLS kernel for 56/64-tap search classes of <= N
+ * items (not measured yet).  Decoder: SACAMD_DEC_SINGLE=1 every frame group as one launch (the fallback form);
  * SACAMD_DEC_ZERO=0 skips zeroing the decoder's planes.
  */
 #ifndef SAC_AMD_H

@@ -535,8 +535,14 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
       // statistics slot: the final pass runs its 33..64-tap items on the four-wave panel kernels (launch_ols), the search on the
       // one-wave kernels: two kernel instances of one capacity class -> slots 8 + k for the former
-      Trace tr(c, st, "ols", (want_pred && k >= 3 && k <= 6) ? 8 + k : k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
-      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, want_pred);
+      // SACAMD_OLS_SMALL_PANEL=N (experiment for the next round, off by default): a 56- / 64-tap class of the SEARCH with at most N
+      // items takes the four-wave panel kernel too.  At those lengths the one-wave kernel is only 1.15-1.27x ahead in saturated
+      // throughput but 2.5x behind in per-step latency, and in the first generations such a class (a few hundred items, fewer
+      // than the chip has slots) is the last OLS kernel to finish: 6.4 s for 381 items (profiles/r03/README.md).
+      static const int small_panel = [] { const char *e = std::getenv("SACAMD_OLS_SMALL_PANEL"); return e ? std::atoi(e) : 0; }();
+      const bool panel_k = want_pred || (small_panel > 0 && (k == 5 || k == 6) && (int)idx_ols[k].size() <= small_panel);
+      Trace tr(c, st, "ols", (panel_k && k >= 3 && k <= 6) ? 8 + k : k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
+      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, panel_k);
     }
     HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
     HIPCHK(c, hipStreamWaitEvent(side[kMark], c->ev_ols[k], 0));
