@@ -1042,6 +1042,130 @@ struct DDS {
 };
 
 // =====================================================================================
+// The two other searchers FrameCoder::Optimize can be given (libsac.cpp:408-415): OptDE (opt/de.cpp:10-184, opt/de.h) and
+// OptCMA (opt/cma.cpp:6-92, opt/cma.h).  Both reuse the draws, gen_norm and reflect of the class above (Opt base, opt/opt.cpp);
+// fused multiply-adds as the reference build contracts them (checked bit for bit against oracle/_ref: tests/golden r4).
+// =====================================================================================
+struct DE : DDS {
+  // DECfg defaults (de.h:19-31): NP 30, CR 0.5, F 0.5, c 0.1, CURPBEST, INIT_NORM, pbest 0.1 -> npbest = clamp(round(3) - 1, 0, 29) = 2
+  static constexpr int NP = 30, NPBEST = 2;
+  using Point = std::pair<double, std::vector<double>>;
+  double gen_CR(double mCR) { return std::min(std::max(std::fma(rnorm(), 0.1, mCR), 0.01), 1.0); }       // normal_distribution{mCR, 0.1}: ret * sd + mean, fused
+  double gen_F(double mF) {                                                                              // cauchy_distribution{mF, 0.1} (bits/random.tcc): a + b * tan(pi * u), unfused
+    double u;
+    do u = r01(); while (u == 0.5);
+    const double pi = 3.1415926535897932384626433832795029L;
+    return std::min(std::max(mF + 0.1 * std::tan(pi * u), 0.01), 1.0);
+  }
+  std::vector<int> select_k_unique_except(int n, int ie, int k) {                                        // de.cpp:12-29
+    std::vector<int> r;
+    if (k >= n - 1) return r;
+    std::vector<int> e;
+    for (int i = 0; i < n; i++) if (i != ie) e.push_back(i);
+    for (int i = 0; i < k; i++) { const int idx = (int)ruint(0, (uint32_t)e.size() - 1); r.push_back(e[idx]); e.erase(e.begin() + idx); }
+    return r;
+  }
+  template <class F> Point run(F &&f, const std::vector<double> &xs) {                                   // de.cpp:77-164
+    int nfunc = 1;
+    Point xb{f(xs), xs};
+    std::vector<Point> pop(NP);
+    pop[0] = xb;
+    for (int a = 1; a < NP; a++) {                                                                       // gen_norm_samples (opt.cpp:125-133)
+      std::vector<double> xt(ndim);
+      for (int i = 0; i < ndim; i++) xt[i] = gen_norm(xb.second[i], pb[i], sigma_init);
+      pop[a].second = xt;
+    }
+    for (int a = 1; a < NP; a++) { pop[a].first = f(pop[a].second); nfunc++; }                            // the whole start-up population, whatever nfunc_max
+    for (int a = 1; a < NP; a++) if (pop[a].first < xb.first) xb = pop[a];
+    double mCR = 0.5, mF = 0.5;
+    while (nfunc < nfunc_max) {
+      std::sort(pop.begin(), pop.end(), [](const Point &a, const Point &b) { return a.first < b.first; });
+      const int agents = std::min(nfunc_max - nfunc, (int)pop.size());
+      std::vector<Point> gen(agents);
+      std::vector<std::pair<double, double>> mut(agents);
+      for (int ia = 0; ia < agents; ia++) {                                                              // generate_candidate, de.cpp:31-70
+        const double tCR = gen_CR(mCR), tF = gen_F(mF);
+        const int R = (int)ruint(0, ndim - 1);
+        const std::vector<int> v = select_k_unique_except((int)pop.size(), ia, 2);
+        const int np = std::min(NPBEST, (int)pop.size() - 1);
+        const int xp = np > 0 ? (int)ruint(0, np) : 0;
+        const std::vector<double> &pbest = pop[xp].second, &cur = pop[ia].second, &x1 = pop[v[0]].second, &x2 = pop[v[1]].second;
+        std::vector<double> xm(ndim), xt(ndim);
+        for (int i = 0; i < ndim; i++)                                                                   // mut_curbest, de.cpp:176-184
+          xm[i] = reflect(std::fma(tF, x1[i] - x2[i], std::fma(tF, pbest[i] - cur[i], cur[i])), pb[i].xmin, pb[i].xmax);
+        for (int i = 0; i < ndim; i++) xt[i] = (r01() < tCR || i == R) ? xm[i] : cur[i];
+        gen[ia].second = xt; mut[ia] = {tCR, tF};
+      }
+      for (int ia = 0; ia < agents; ia++) { gen[ia].first = f(gen[ia].second); nfunc++; }
+      std::vector<double> crs, fs;
+      for (int ia = 0; ia < agents; ia++)
+        if (gen[ia].first < pop[ia].first) {
+          pop[ia] = gen[ia]; crs.push_back(mut[ia].first); fs.push_back(mut[ia].second);
+          if (pop[ia].first < xb.first) xb = pop[ia];
+        }
+      if (nfunc >= nfunc_max) break;
+      double mean = 0.0, lehmer = 0.0;                                                                   // MathUtils::mean / meanL, utils.h:283-305
+      if (!crs.empty()) { double sum = 0.0; for (double v2 : crs) sum += v2; mean = sum / static_cast<double>(crs.size()); }
+      if (!fs.empty()) {
+        double s0 = 0.0, s1 = 0.0; size_t k = 0;
+        for (; k + 4 <= fs.size(); k += 4) for (size_t q = k; q < k + 4; q++) { s0 = s0 + fs[q] * fs[q]; s1 += fs[q]; }   // vectorised squares, in-order adds
+        for (; k < fs.size(); k++) { s0 = std::fma(fs[k], fs[k], s0); s1 += fs[k]; }
+        if (s1 > 0.0) lehmer = s0 / s1;
+      }
+      mCR = std::fma(mean, 0.1, (1.0 - 0.1) * mCR);
+      mF = std::fma(lehmer, 0.1, (1.0 - 0.1) * mF);
+    }
+    return xb;
+  }
+};
+
+struct CMA : DDS {
+  template <class F> std::pair<double, std::vector<double>> run(F &&f, const std::vector<double> &xs) {  // cma.cpp:49-92
+    const int n = ndim;
+    const double d = 1.0 + n / 2.0, p_t = 2.0 / 11.0, cp = 1.0 / 12.0, cc = 2.0 / (n + 2.0), ccov = 2.0 / (n * n + 6.0);   // CMAParams, cma.h:17-38
+    std::vector<double> pc(n, 0.0), mcov((size_t)n * n, 0.0), G((size_t)n * n, 0.0), az(n), z(n), xg(n);
+    for (int i = 0; i < n; i++) mcov[(size_t)i * n + i] = 1.0;
+    double sigma = sigma_init, p_succ = p_t;                    // SSC1(p_target, cp, 1/d), ssc.h:43-60 (bounds 0.05 .. 0.25)
+    std::pair<double, std::vector<double>> xb{f(xs), xs};
+    int nfunc = 1;
+    auto fold_sub = [](double acc, int m, const double *a, const double *b) {   // in-order reduction as the vectorised loop runs it
+      int k = 0;
+      for (; k + 4 <= m; k += 4) { acc = acc - a[k] * b[k]; acc = acc - a[k + 1] * b[k + 1]; acc = acc - a[k + 2] * b[k + 2]; acc = acc - a[k + 3] * b[k + 3]; }
+      if (m - k >= 2) { acc = acc - a[k] * b[k]; acc = acc - a[k + 1] * b[k + 1]; k += 2; }
+      if (k < m) acc = std::fma(-a[k], b[k], acc);
+      return acc;
+    };
+    while (nfunc < nfunc_max) {
+      // slmath::Cholesky::Factor(mcov, 0.1) (math.h:89-111); a failure leaves G half-updated and is ignored, as in the reference
+      for (int i = 0; i < n; i++) std::copy_n(&mcov[(size_t)i * n], i + 1, &G[(size_t)i * n]);
+      for (int i = 0; i < n; i++) {
+        double *gi = &G[(size_t)i * n];
+        for (int j = 0; j < i; j++) { const double *gj = &G[(size_t)j * n]; gi[j] = fold_sub(gi[j], j, gi, gj) / gj[j]; }
+        const double s = fold_sub(gi[i] + 0.1, i, gi, gi);
+        if (s > 1E-8) gi[i] = std::sqrt(s); else break;
+      }
+      for (int i = 0; i < n; i++) z[i] = rnorm();
+      for (int i = 0; i < n; i++) az[i] = dot_ref(&G[(size_t)i * n], z.data(), (size_t)n);                         // slmath::mul(G, z)
+      for (int i = 0; i < n; i++) xg[i] = reflect(std::fma((pb[i].xmax - pb[i].xmin) * sigma, az[i], xb.second[i]), pb[i].xmin, pb[i].xmax);
+      const double fn = f(xg);
+      const double lam = fn < xb.first ? 1.0 : 0.0;
+      p_succ = std::fma(1.0 - cp, p_succ, cp * lam);
+      sigma = sigma * std::exp((1.0 / d) * (p_succ - p_t) / (1.0 - p_t));
+      sigma = std::min(std::max(sigma, 0.05), 0.25);
+      if (fn < xb.first) {
+        xb = {fn, xg};
+        const double a = 1.0 - cc, b = std::sqrt(cc * (2.0 - cc));                                        // update_cov, cma.cpp:45-49
+        for (int i = 0; i < n; i++) pc[i] = std::fma(a, pc[i], b * az[i]);
+        for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) mcov[(size_t)j * n + i] = std::fma(1.0 - ccov, mcov[(size_t)j * n + i], ccov * (pc[j] * pc[i]));
+      }
+      nfunc++;
+    }
+    return xb;
+  }
+};
+static int g_orc_search = 0;     // FrameCoder::SearchMethod of the next orc_encode_frame calls: 0 DDS, 1 DE, 2 CMA
+
+// =====================================================================================
 // frame statistics, encode and decode (libsac.cpp:201-298,429-479,507-593,626-651)
 // =====================================================================================
 static void analyse(const int32_t *src, int n, int32_t *mean, int32_t *mn, int32_t *mx) {
@@ -1094,14 +1218,17 @@ static int encode_frame(int nch, int framesize, int n, const int32_t *raw, const
       predict_frame(nch, n, smp.data(), stats.data(), g, start, nopt, true, rc.optk, err.data(), nullptr, nullptr);
       double c = 0.0;
       for (int ch = 0; ch < nch; ch++) c += cost(rc.cost, err.data() + (size_t)ch * nopt, nopt);
-      if (neval < rc.maxnfunc) {
+      if (neval < rc.maxnfunc + (g_orc_search ? 32 : 0)) {      // DE evaluates its whole start-up population (30 points) even when maxnfunc is smaller
         if (trace_cost) trace_cost[neval] = c;
         if (trace_coefs) std::memcpy(trace_coefs + (size_t)neval * 58, g, sizeof(g));
       }
       neval++;
       return c;
     };
-    auto best = dds.run(f, xs);
+    std::pair<double, std::vector<double>> best;
+    if (g_orc_search == 1) { DE de; static_cast<DDS &>(de) = dds; best = de.run(f, xs); }           // cmdline.cpp:221-241: same maxnfunc / sigma
+    else if (g_orc_search == 2) { CMA cma; static_cast<DDS &>(cma) = dds; best = cma.run(f, xs); }
+    else best = dds.run(f, xs);
     for (int i = 0; i < ndim; i++) base.c[lp[i]].vdef = (float)best.second[i];
   }
   for (int i = 0; i < 58; i++) coefs[i] = base.c[i].vdef;
@@ -1344,6 +1471,7 @@ API void orc_gen_norm(double x, double xmin, double xmax, double r, int n, doubl
   DDS d; Box b{xmin, xmax};
   for (int i = 0; i < n; i++) out[i] = d.gen_norm(x, b, r);
 }
+API void orc_set_search_method(int search) { g_orc_search = search; }
 API double orc_reflect(double x, double xmin, double xmax) { return DDS::reflect(x, xmin, xmax); }
 API void orc_ssc(int which, int n, const double *lam, double sigma0, double *out) {
   double sigma = sigma0; int nsucc = 0, nfail = 0; double p_succ = 0.05;

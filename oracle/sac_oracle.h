@@ -55,6 +55,9 @@ double orc_dds_quadratic(int ndim, const double *xmin, const double *xmax, const
 int orc_encode_frame(int nch, int framesize, int n, const int32_t *raw, const orc_frame_cfg *rc,
                      float *profile_io, uint8_t *out, int cap, double *trace_cost,
                      float *trace_coefs, int *info);
+/* FrameCoder::SearchMethod for the following orc_encode_frame calls: 0 DDS (default), 1 DE (opt/de.cpp), 2 CMA (opt/cma.cpp);
+ * with 1 / 2 the trace arrays must hold maxnfunc + 32 entries */
+void orc_set_search_method(int search);
 int orc_decode_frame(const uint8_t *rec, int len, int nch, int framesize, int32_t *out,
                      int cap_samples, float *coefs_out);
 double orc_dot(const double *x, const double *y, int n);

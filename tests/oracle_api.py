@@ -244,10 +244,7 @@ class Checker:
     # ---- whole frame
     def encode_frame(self, raw, cfg: FrameCfg, framesize, profile=None, trace=False, search=0):
         """search: FrameCoder::SearchMethod 0 DDS, 1 DE, 2 CMA (the two latter with the genuine-reference checker only)."""
-        if search:
-            assert self.prefix == "ref", "DE / CMA searches exist in oracle/_ref only"
-        if self.prefix == "ref":
-            self.lib.ref_set_search_method(int(search))
+        getattr(self.lib, f"{self.prefix}_set_search_method")(int(search))
         raw = np.ascontiguousarray(raw, np.int32)
         nch, n = raw.shape
         prof = self.profile()[:, 2].copy() if profile is None else np.ascontiguousarray(profile, np.float32).copy()

@@ -169,3 +169,17 @@ def test_wide_material_records_vs_golden(orc, golden_r4, name):
         assert np.array_equal(r["trace_cost"][: cfg.maxnfunc], golden_r4[f"wide/{name}/trace_cost"][: cfg.maxnfunc])
     dec, _ = orc.decode_frame(r["record"], raw.shape[0], FRAMESIZE)
     assert np.array_equal(dec, raw)
+
+
+@pytest.mark.parametrize("name", list(__import__("golden_cases").search_cases().keys()))
+def test_de_and_cma_records_vs_golden(orc, golden_r4, name):
+    """--opt-cfg=de / cma: the oracle's own restatement of OptDE::run / OptCMA::run (sac_oracle.cpp) reproduces the records,
+    chosen profiles and every search cost of oracle/_ref (DriverDE / DriverCMA around the genuine Opt, Cholesky, SSC1)."""
+    from golden_cases import search_cases
+    raw, cfg, search = search_cases()[name]
+    r = orc.encode_frame(raw, cfg, FRAMESIZE, trace=True, search=search)
+    assert r["record"] == golden_r4[f"search/{name}/record"].tobytes()
+    assert np.array_equal(r["profile"], golden_r4[f"search/{name}/profile"])
+    want = golden_r4[f"search/{name}/trace_cost"]
+    assert len(r["trace_cost"]) == len(want) and np.array_equal(r["trace_cost"], want)
+    orc.lib.orc_set_search_method(0)
