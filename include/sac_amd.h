@@ -219,6 +219,10 @@ int sacamd_debug_predict(sacamd_ctx *ctx, int frame, const float *coefs, int sta
                          int optimize, int optk, double *plpc, double *psum, int32_t *err, int32_t *pred);
 /* bitplane coder on an arbitrary s2u vector (== BitplaneCoder::Encode + RangeCoderSH) */
 int sacamd_debug_bitplane(sacamd_ctx *ctx, const int32_t *s2u, int n, int maxbpn, uint8_t *out, int cap, int *len);
+/* the device's exp / pow (the glibc ports every kernel uses where the reference calls std::exp / std::pow) and the in-kernel
+ * BitplaneCoder::PredictLaplace (vle.cpp:70-79) on arbitrary arguments.  kind 0: out = exp(x); 1: out = pow(x, y);
+ * 2: out = PredictLaplace(avg_sum = (uint32)x, bpn = (int)y) */
+int sacamd_debug_libm(sacamd_ctx *ctx, int kind, const double *x, const double *y, int n, double *out);
 /* cost function on an arbitrary residual vector (== CostFunction::Calc, cost.h) */
 int sacamd_debug_cost(sacamd_ctx *ctx, int kind, const int32_t *err, int n, double *cost);
 /* time spent (ms, HIP events on the context's stream) in each kernel family since the last call:

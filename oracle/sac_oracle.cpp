@@ -81,6 +81,10 @@ struct Params {
 };
 
 static inline int iround(float v) { return (int)std::round((double)v); }
+// `(int32_t)std::round(pd)` of libsac.cpp:106 / :154 as the reference's x86-64 build executes it: cvttsd2si returns INT_MIN for
+// values outside the int32 range and for NaN (C++ leaves the conversion undefined; 24-bit material does overshoot past 2^31
+// in the first samples of a frame, and the decoder repeats whatever the encoder's conversion gave)
+static inline int32_t cvt_i32_x86(double r) { return (r >= -2147483648.0 && r < 2147483648.0) ? (int32_t)r : INT32_MIN; }
 
 // libsac.cpp:37-92
 static void set_param(Params &p, const float *g, bool optimize, int optk) {
@@ -541,7 +545,7 @@ static void predict_frame(int nch, int total, const int32_t *samples, const int3
   Predictor pr; pr.init(P, lo, hi);
   auto step = [&](int chp, int ch, int32_t val, int idx) {
     double pd = pr.c[chp].predict();
-    int32_t pi = std::min(std::max((int32_t)std::round(pd), lo[ch]), hi[ch]);
+    int32_t pi = std::min(std::max(cvt_i32_x86(std::round(pd)), lo[ch]), hi[ch]);
     if (tr) {
       tr->pd[(size_t)ch * n + idx] = pd;
       tr->plpc[(size_t)ch * n + idx] = pr.c[chp].p_lpc;
@@ -1302,7 +1306,7 @@ static int decode_frame(const uint8_t *rec, int len, int nch, int framesize, int
   Predictor pr; pr.init(P, lo, hi);
   auto step = [&](int chp, int ch, int32_t *dst, int idx) {
     const double pd = pr.c[chp].predict();
-    const int32_t pi = std::min(std::max((int32_t)std::round(pd), lo[ch]), hi[ch]);
+    const int32_t pi = std::min(std::max(cvt_i32_x86(std::round(pd)), lo[ch]), hi[ch]);
     const int32_t e = err[(size_t)ch * n + idx];
     dst[idx] = mapped[ch] ? pi + maps[ch].unmap(pi + mean[ch], e) : pi + e;
     pr.c[chp].update(dst[idx]);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
     "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
     "sacamd_decode_frames", "sacamd_comm_unique_id", "sacamd_comm_create", "sacamd_comm_destroy", "sacamd_comm_last_error",
-    "sacamd_gather_records", "sacamd_gather_records_via",
+    "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_debug_libm",
 ]
 
 
@@ -415,6 +415,14 @@ class Context:
         ln = c_int(0)
         self._chk(self.lib.sacamd_debug_bitplane(self.h, _vp(u), u.size, maxbpn, _vp(out), out.size, byref(ln)))
         return out[: ln.value].tobytes()
+
+    def debug_libm(self, kind, x, y=None) -> np.ndarray:
+        """device exp (kind 0) / pow (1) / PredictLaplace(avg_sum, bpn) (2) on arrays of arguments"""
+        xa = np.ascontiguousarray(x, np.float64)
+        ya = np.ascontiguousarray(np.zeros_like(xa) if y is None else y, np.float64)
+        out = np.zeros(xa.size)
+        self._chk(self.lib.sacamd_debug_libm(self.h, int(kind), _vp(xa), _vp(ya), xa.size, _vp(out)))
+        return out
 
     def debug_cost(self, kind, err) -> float:
         e = np.ascontiguousarray(err, np.int32)

@@ -113,5 +113,10 @@ SA_HD double tr_s2pow(const double *x, const double *pw, int n) {
 SA_HD double sgnd(double x) { return (double)((x > 0) - (x < 0)); }
 SA_HD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 SA_HD int clampi32(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// (int32_t)double as the reference's x86-64 build performs it (cvttsd2si): a value outside the int32 range -- or a NaN --
+// gives INT_MIN ("integer indefinite"), where gfx950's v_cvt_i32_f64 saturates to INT_MAX on the positive side.  It matters:
+// on 24-bit material the cascade overshoots past 2^31 in the first samples of a frame (libsac.cpp:106 then clamps INT_MIN to
+// the frame's minimum); found on the GPU in round 4 (profiles/r04/bisect24_stages.log).
+SA_HD int cvt_i32_x86(double r) { return (r >= -2147483648.0 && r < 2147483648.0) ? (int)r : (-2147483647 - 1); }
 
 }  // namespace sacamd

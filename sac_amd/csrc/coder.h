@@ -509,8 +509,9 @@ SA_HD void map_code(MapModel &m, U *ul, U *uh, const CoderTabs &T, RC &rc) {
 template <class E>
 SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned char *used /*nullable: usedl, usedh*/,
                        const unsigned short *laplace, const short *g_fwd, const unsigned short *g_inv, const unsigned short *plap_init,
-                       CntL *csig0, unsigned char *out, int cap, CoderModel &M, const CoderTabs &T, CoderWin &W, MapModel &MM) {
-  (void)g_fwd; (void)g_inv;
+                       CntL *csig0, unsigned char *out, int cap, CoderModel &M, const CoderTabs &T, CoderWin &W, MapModel &MM,
+                       int serial_chain = 0 /*device, parity tap: run the decision chain on lane 0 (coder_step) instead of coder_step_wave*/) {
+  (void)g_fwd; (void)g_inv; (void)serial_chain;
   // T (read-only tables) has been staged by the caller (coder_tabs_init) and may be shared by
   // several streams of one workgroup
   ex.par([&](int l) {
@@ -561,8 +562,10 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
       // The store of a decision's csig0 update is issued at the start of the following decision,
       // right before that prefetch: both then have a whole decision to complete, and the prefetch,
       // issued after the store, observes it.
+      bool chain_done = false;
 #if defined(__HIPCC__)
-      if constexpr (E::is_device) {
+      if constexpr (E::is_device) if (!serial_chain) {
+        chain_done = true;
         ex.par([&](int l) {
           unsigned *cs = reinterpret_cast<unsigned *>(csig0);
           // csig0 index of decision k (-1: a refinement decision), from the lane that described it
@@ -587,9 +590,9 @@ SA_HD int coder_stream(E &ex, const int *s2u, int n, int maxbpn, const unsigned 
           }
           if (l == 0) { if (pend) cs[pidx] = pval; publish(); }
         });
-      } else
+      }
 #endif
-      {
+      if (!chain_done) {
         ex.lane0([&]() {
           CoderDescR D{ex.lane_geti(da, 0), ex.lane_geti(db, 0), ex.lane_geti(dc, 0), ex.lane_geti(dd, 0)};
           int idx = (D.a >> 16) & 0xffff;

@@ -1036,6 +1036,23 @@ API int sacamd_debug_cost(sacamd_ctx *c, int kind, const int32_t *err, int n, do
   return 0;
 }
 
+// parity tap: the device's exp / pow ports (libm_port.h) and the in-kernel PredictLaplace (coder.h: laplace_direct)
+API int sacamd_debug_libm(sacamd_ctx *c, int kind, const double *x, const double *y, int n, double *out) {
+  if (!c || !x || !out || n < 0 || kind < 0 || kind > 2 || (kind && !y)) return SACAMD_ERR_ARG;
+  if (!n) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf<double> d;
+  HIPCHK(c, d.ensure((size_t)3 * n));
+  HIPCHK(c, hipMemcpy(d.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  if (y) HIPCHK(c, hipMemcpy(d.p + n, y, sizeof(double) * n, hipMemcpyHostToDevice));
+  launch_libm_tap(c->stream, kind, d.p, d.p + n, n, d.p + 2 * (size_t)n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, d.p + 2 * (size_t)n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  d.release();
+  return 0;
+}
+
 // debug: enable (on!=0) / read the OLS kernel's section cycle counters of the last launch
 
 // ================================================================== (7) adaptive sub-frame split

@@ -71,6 +71,7 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
                   unsigned char *d_compact = nullptr /*nullable: every finished stream appends its payload here (16-byte aligned)*/,
                   long long *d_compact_at = nullptr /*[count] offset of each payload in d_compact, [count] = bytes used (zeroed by the launcher)*/);
 size_t coder_state_bytes();
+void launch_libm_tap(hipStream_t s, int kind, const double *d_x, const double *d_y, int n, double *d_out);   // parity tap (sacamd_debug_libm)
 struct DecJob {
   long long off_in;     // bytes into d_in (the channel's payload)
   long long off_out;    // ints into d_err

@@ -2,6 +2,7 @@
 // sparse-PCM residual remap (Remap::Map + CalcRemapError, map.cpp:175-187, libsac.cpp:230-251).
 #include "coder.h"
 #include <atomic>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace sacamd {
@@ -24,7 +25,7 @@ size_t coder_state_bytes() { return sizeof(CntL) * 65536; }
 __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJob *jobs, int count, const int *s2u, const int *s2u_map, const unsigned char *used,
                                                const unsigned short *laplace, const short *gfwd, const unsigned short *ginv,
                                                unsigned char *state, size_t stride, unsigned char *out, int *len,
-                                               const int *mb, unsigned char *compact, long long *compact_at) {
+                                               const int *mb, unsigned char *compact, long long *compact_at, int serial_chain) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CoderTabs &T = *reinterpret_cast<CoderTabs *>(smem + CoderLdsLayout::o_tabs);
   coder_tabs_init(T, gfwd, ginv, (int)threadIdx.x, (int)blockDim.x);
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(64 * kCoderStreamsPerWg) void k_coder(const CoderJo
   ExecDevWave ex;
   const int *src = job.with_map ? s2u_map : s2u;       // remapped residual stream for the MapEncoder variant
   const int l = coder_stream(ex, src + job.off_in, job.n, job.maxbpn, job.with_map ? used + job.off_used : nullptr, laplace, gfwd, ginv,
-                             plap, csig0, out + job.off_out, job.cap, M, T, W, MM);
+                             plap, csig0, out + job.off_out, job.cap, M, T, W, MM, serial_chain);
   const int lane = threadIdx.x & 63;
   if (lane == 0) len[ji] = l;
   if (compact) {
@@ -85,8 +86,10 @@ void launch_coder(hipStream_t s, const CoderJob *d_jobs, int count, const int *d
   int spw = 1;
   if (count > 512) { spw = 3; while (spw < kCoderStreamsPerWg && count > 256 * spw) spw++; }
   const int wgs = (count + spw - 1) / spw;
+  // parity tap: SACAMD_CODER_SERIAL=1 runs every decision on lane 0 with the body the CPU emulation runs (coder_step)
+  static const int serial_chain = [] { const char *e = std::getenv("SACAMD_CODER_SERIAL"); return (e && e[0] == '1') ? 1 : 0; }();
   hipLaunchKernelGGL(k_coder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_s2u, d_s2u_map, d_used, d_laplace,
-                     d_fwd, d_inv, d_state, state_stride, d_out, d_len, d_maxbpn, d_compact, d_compact_at);
+                     d_fwd, d_inv, d_state, state_stride, d_out, d_len, d_maxbpn, d_compact, d_compact_at, serial_chain);
 }
 
 // ------------------------------------------------------------------ entropy DEcoder (FrameCoder::DecodeMonoFrame, libsac.cpp:280-298)
@@ -137,6 +140,19 @@ void launch_decoder(hipStream_t s, const DecJob *d_jobs, int count, const unsign
   const int wgs = (count + spw - 1) / spw;
   hipLaunchKernelGGL(k_decoder, dim3(wgs), dim3(64 * spw), CoderLdsLayout::bytes(spw), s, d_jobs, count, d_in, d_err, d_used, d_laplace,
                      d_fwd, d_inv, d_state, state_stride, d_consumed);
+}
+
+
+// ------------------------------------------------------------------ parity tap: the device's exp / pow ports and PredictLaplace
+// kind 0: sa_exp(x)  1: sa_pow(x, y)  2: laplace_direct((unsigned)x, (int)y) as a double
+__global__ void k_libm_tap(int kind, const double *x, const double *y, int n, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = kind == 0 ? sa_exp(x[i]) : kind == 1 ? sa_pow(x[i], y[i]) : (double)laplace_direct((unsigned)x[i], (int)y[i]);
+}
+void launch_libm_tap(hipStream_t s, int kind, const double *d_x, const double *d_y, int n, double *d_out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_libm_tap, dim3((n + 255) / 256), dim3(256), 0, s, kind, d_x, d_y, n, d_out);
 }
 
 // ------------------------------------------------------------------ remap

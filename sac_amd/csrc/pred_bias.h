@@ -81,7 +81,7 @@ SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *
     const double pbias = dot_canon(pt, mw, 3);
     const double pd = px + pbias;
     // eprocess (libsac.cpp:105-109)
-    const int pi = clampi32((int)round(pd), p.out_lo, p.out_hi);
+    const int pi = clampi32(cvt_i32_x86(round(pd)), p.out_lo, p.out_hi);
     int v;
     if (dec) {
       const int e = dec->merr[t];

@@ -163,6 +163,9 @@ API long emu_laplace_mismatches(long n, int seed) {
   return bad;
 }
 
+// canon.h: the double -> int32 conversion of libsac.cpp:106 as the reference's x86-64 build executes it
+API int emu_cvt_i32(double r) { return cvt_i32_x86(r); }
+
 // decode side: bytes -> s2u values (+ used flags when with_map); returns bytes consumed
 API int emu_bitplane_decode(const unsigned char *in, int inlen, int n, int maxbpn, unsigned char *used_out, const int *fwd_i, const int *inv_i, int32_t *s2u) {
   static std::vector<unsigned short> lap; static unsigned short plap[32];

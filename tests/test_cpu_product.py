@@ -131,6 +131,31 @@ def test_coder_body_on_wide_material_vs_oracle(emu, orc):
         assert np.array_equal(dec, u)
 
 
+def test_prediction_conversion_follows_the_x86_reference(emu, orc):
+    """`(int32_t)std::round(pd)` (libsac.cpp:106): outside the int32 range the reference's x86-64 build yields INT_MIN (cvttsd2si),
+    which the clamp turns into the frame minimum; gfx950's conversion saturates instead, so the product spells the x86 result
+    out (canon.h: cvt_i32_x86).  24-bit material reaches |pd| > 2^31 in the first samples of a frame: the kernel body on such a
+    frame equals the oracle, whose residual there is val - minval."""
+    emu.emu_cvt_i32.argtypes = [ctypes.c_double]
+    lo = -(1 << 31)
+    for v, want in ((2250366745.0, lo), (-3e9, lo), (float("nan"), lo), (float("inf"), lo), (2147483647.0, 2147483647), (2147483648.0, lo),
+                    (-2147483648.0, lo), (-2147483649.0, lo), (12345.0, 12345), (-7.0, -7)):
+        assert emu.emu_cvt_i32(v) == want, v
+    from golden_cases import wide_cases
+    raw, _ = wide_cases()["s24_normal"]
+    smp, stats = center_frame(raw)
+    prof = orc.profile()[:, 2].copy()
+    n = raw.shape[1]
+    pd, _, _, oerr = orc.predict_trace(smp, stats, prof, 0, n, 0)
+    over = np.abs(pd) >= 2.0 ** 31
+    assert over.any()                                   # the case exists in this frame (ch0, samples 19..21)
+    assert np.array_equal(oerr[over], (smp - np.asarray(stats).reshape(-1, 3)[:, :1])[over])      # INT_MIN clamped to minval
+    plpc = np.zeros((2, n)); psum = np.zeros((2, n)); err = np.zeros((2, n), np.int32); pred = np.zeros((2, n), np.int32)
+    rc = emu.emu_predict(2, n, _vp(np.ascontiguousarray(smp, np.int32)), _vp(np.ascontiguousarray(stats, np.int32)),
+                         _vp(np.ascontiguousarray(prof, np.float32)), 0, n, 0, 4, _vp(plpc), _vp(psum), _vp(err), _vp(pred))
+    assert rc == 0 and np.array_equal(err, oerr)
+
+
 def test_host_dds_driver_matches_reference_search(emu, golden):
     nd = 12
     lo = np.zeros(nd); hi = np.arange(1, nd + 1) * 1.0

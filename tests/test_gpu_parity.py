@@ -679,6 +679,58 @@ def test_decode_cli_restores_the_wav_files(api, tmp_path):
         assert out2.read_bytes() == blob
 
 
+def test_device_libm_and_predict_laplace_taps(api):
+    """The device's exp / pow ports (libm_port.h; every kernel calls them where the reference calls std::exp / std::pow) and the
+    in-kernel BitplaneCoder::PredictLaplace (coder.h: laplace_direct, vle.cpp:70-79) against the host libm of this box, bit for
+    bit -- including pow's underflow / subnormal side (theta^(2^bpn) for small avg_sum) and exp arguments near 0."""
+    import math
+    ctx = api.Context(1, 1024, 1)
+    rng = np.random.default_rng(1)
+    x = np.concatenate([-1.0 / rng.integers(1, 1 << 25, 100000), -rng.uniform(0, 800, 50000), rng.uniform(-1e-9, 1e-9, 1000),
+                        -10.0 ** rng.uniform(-12, 3, 50000), rng.uniform(-745.2, -707.0, 20000)])
+    want = np.array([math.exp(v) for v in x])
+    assert np.array_equal(ctx.debug_libm(0, x).view(np.uint64), want.view(np.uint64))
+    avg = np.concatenate([rng.integers(1, 1 << 25, 150000), rng.integers(1, 1 << 14, 50000)])
+    th = np.array([math.exp(-1.0 / a) for a in avg]); yy = 2.0 ** rng.integers(0, 25, avg.size)
+    want = np.array([math.pow(a, b) for a, b in zip(th, yy)])
+    assert (want == 0).any() and ((want > 0) & (want < 2.3e-308)).any()          # underflow and subnormal results are in the sample
+    assert np.array_equal(ctx.debug_libm(1, th, yy).view(np.uint64), want.view(np.uint64))
+    xs = rng.uniform(1e-3, 1e7, 100000); ys = -rng.uniform(0.0, 2.0, xs.size)     # the OLS stage's (esum + beta_add)^-beta_pow
+    want = np.array([math.pow(a, b) for a, b in zip(xs, ys)])
+    assert np.array_equal(ctx.debug_libm(1, xs, ys).view(np.uint64), want.view(np.uint64))
+
+    def host_laplace(a, b):
+        p_l = 0.0
+        if a > 0:
+            p_l = 1.0 - 1.0 / (1 + math.pow(math.exp(-1.0 / a), float(1 << b)))
+        return min(max(int(math.floor(p_l * 32768 + 0.5)), 1), 32767)
+    avg = np.concatenate([rng.integers(0, 1 << 25, 150000), np.arange(0, 4096), 1 << np.arange(0, 25), (1 << np.arange(1, 25)) - 1])
+    bp = rng.integers(0, 25, avg.size)
+    want = np.array([host_laplace(int(a), int(b)) for a, b in zip(avg, bp)], np.float64)
+    assert np.array_equal(ctx.debug_libm(2, avg.astype(np.float64), bp.astype(np.float64)), want)
+    ctx.close()
+
+
+def test_24bit_predictor_stages_vs_oracle(api, orc):
+    """24-bit input through the three predictor stages (final pass): p_lpc and p_lpc + p_lms bit-identical, residuals equal --
+    including the samples where the prediction leaves the int32 range (round-3 defect: the device conversion saturated to
+    INT_MAX where the reference's x86 conversion gives INT_MIN, libsac.cpp:106)."""
+    raw, _ = wide_cases()["s24_normal"]
+    smp, stats = center_frame(raw)
+    prof = api.default_profile()[:, 2].copy()
+    n = raw.shape[1]
+    pd, oplpc, oplms, oerr = orc.predict_trace(smp, stats, prof, 0, n, 0)
+    assert (np.abs(pd) >= 2.0 ** 31).any()
+    ctx = api.Context(2, FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    ctx.analyse(api.make_cfg("normal", sparse_pcm=0))
+    plpc, psum, err, pred = ctx.debug_predict(0, prof, 0, n, 0, 4)
+    ctx.close()
+    assert np.array_equal(plpc.view(np.uint64), oplpc.view(np.uint64))
+    assert np.array_equal(psum.view(np.uint64), (oplpc + oplms).view(np.uint64))
+    assert np.array_equal(err, oerr)
+
+
 @pytest.mark.parametrize("name", list(wide_cases().keys()))
 def test_24bit_material_records_vs_golden(api, golden_r4, name):
     """24-bit material (|sample| up to 2^23, --sparse-pcm=0; SURVEY 8f rank 3 remainder): byte-identical frame records and
