@@ -16,12 +16,10 @@
  * gfx950 device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
  *
  * Environment switches (read once per process).  SACAMD_TRACE=1 prints every predictor launch with its duration and start
- * offset.  A/B measurements: SACAMD_CANON_SYSTOLIC=1 the round-2 cascade layouts for the final pass;
- * SACAMD_OLS_FINAL_PANEL=0 the one-wave OLS kernel for it; SACAMD_LMS_STREAMS=0 cascade launches round-robin over four streams;
- * SACAMD_FINAL_GROUPS=1 final-pass cascade launches grouped by OLS class; SACAMD_TAIL_STREAMS=1 a stream set of its own for the
- * final pass (software-pipelined batches); SACAMD_OLS_SMALL_PANEL=N the panel OLS kernel for 56/64-tap search classes of <= N
- * items (not measured yet).  Decoder: SACAMD_DEC_SINGLE=1 every frame group as one launch (the fallback form);
- * SACAMD_DEC_ZERO=0 skips zeroing the decoder's planes.
+ * offset.  SACAMD_OLS_FINAL_PANEL=0 runs the final pass's 33..64-tap items on the one-wave OLS kernel.  Parity taps:
+ * SACAMD_CODER_SERIAL=1 runs the coder's decision chain on one lane (the body the CPU emulation runs).  Decoder:
+ * SACAMD_DEC_SINGLE=1 every frame group as one launch (the fallback form); SACAMD_DEC_ZERO=0 skips zeroing the decoder's planes.
+ * (The scheduling experiments of rounds 2-3 that measured as losses -- DESIGN.md 9 -- are no longer selectable.)
  */
 #ifndef SAC_AMD_H
 #define SAC_AMD_H
@@ -185,9 +183,13 @@ int sacamd_assign_frames(const double *cost, int nframes, int world, int *owner)
  * (back to back in recs, rec_off[i]..rec_off[i+1] delimit record i, as sacamd_encode_frames writes them) with their
  * global frame numbers frame_id[i]; the ranks' frame ids must partition 0..total_frames-1.  Rank 0 receives all
  * records in frame order in out (capacity cap bytes) with out_off[total_frames+1]; other ranks may pass NULL / 0.
- * Wire traffic: one all-gather of (count, bytes), one all-gather of (frame, length) pairs, then ONE group of
- * ncclSend / ncclRecv (rank 0 posts a receive per peer inside a single ncclGroupStart/End, so its xGMI links fill
- * concurrently); payloads are staged through device buffers owned by the communicator. */
+ * Wire traffic: one all-gather of (count, bytes, status, rank 0's capacity), one all-gather of (frame, length) pairs, then ONE
+ * group of ncclSend / ncclRecv (rank 0 posts a receive per peer inside a single ncclGroupStart/End, so its xGMI links fill
+ * concurrently); payloads are staged through device buffers owned by the communicator.
+ * Failure behaviour: no rank leaves the call alone.  Bad arguments on ANY rank (incl. rank 0's out / cap) are seen by all
+ * ranks in the first all-gather and all return an error before a payload moves; a rank whose own work failed calls with
+ * nrec = -1 and every rank returns SACAMD_ERR_COMM ("rank r reported a failure").  After a HIP / RCCL error under the gather
+ * the communicator is aborted (ncclCommAbort), so that peers blocked in the collective return, and must be destroyed. */
 typedef struct sacamd_comm sacamd_comm;
 #define SACAMD_COMM_ID_BYTES 128
 int sacamd_comm_unique_id(uint8_t *id128);

@@ -12,7 +12,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_longlong, c_void
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsac_amd.so")
+LIB_PATH = os.environ.get("SACAMD_LIB_PATH") or os.path.join(HERE, "libsac_amd.so")   # override: A/B builds of the library (tools/build_variant.sh)
 NUM_COEFS = 58
 COST_L1, COST_RMS, COST_ENTROPY, COST_GOLOMB, COST_BITPLANE = 0, 1, 2, 3, 4
 SEARCH_DDS, SEARCH_DE, SEARCH_CMA = 0, 1, 2

@@ -1,26 +1,71 @@
 // sac_amd/csrc/framecoder.h -- FrameCoder-shaped C++ host wrapper over the C ABI (include/sac_amd.h).
 //
-// Mirrors the public surface of the reference's FrameCoder (/root/reference/src/libsac/libsac.h:12-83)
-// for the ENCODE path so that Codec::EncodeFile (libsac/libsac.cpp:782-855) can drive it unchanged:
-//   FrameCoder(numchannels, framesize, cfg); samples[ch][0..n); SetNumSamples(n); Predict();
-//   Encode(); WriteEncoded(fout) -- same names, same argument meaning, same public buffers.
-// One frame per Predict()/Encode() pair, like the reference; base_profile is carried from frame to frame
-// unless cfg.ocfg.reset (libsac.cpp:461-466), so a caller that encodes a file frame by frame gets the
-// reference's warm-started searches.  Callers that want many frames in one GPU batch use the C ABI's
-// sacamd_encode_frames directly.
-// Errors: the reference prints and continues or terminates; here every failure throws
-// std::runtime_error with sacamd_last_error() (never across the C ABI, which returns codes).
+// Mirrors the public surface of the reference's FrameCoder (/root/reference/src/libsac/libsac.h:12-83) so that
+// Codec::EncodeFile (libsac/libsac.cpp:782-855) and Codec::DecodeFile (:857-883) can drive it unchanged:
+//   encode: FrameCoder(numchannels, framesize, cfg); samples[ch][0..n); SetNumSamples(n); Predict(); Encode(); WriteEncoded(fout)
+//   decode: ReadEncoded(fin); Decode(); Unpredict(); samples[ch][0..GetNumSamples())
+// -- same names, same argument meaning, same public buffers (samples, error, s2u_error, s2u_error_map, pred as
+// vector<vector<int32_t>>; encoded / enc_temp1 / enc_temp2 as vector<BufIO>; framestats), and the types the reference's callers
+// touch: BufIO (common/bufio.h:7-26), SacProfile with coefs{vmin,vmax,vdef} (libsac/profile.h:61-109; base_profile is public
+// here, the reference keeps it private).  WriteEncoded / ReadEncoded take anything with a `file` stream member and
+// ReadData / WriteData -- i.e. the reference's AudioFile (file/file.h:10-36) as it is -- or a plain std::ostream / std::istream.
+// One frame per Predict()/Encode() pair, like the reference; base_profile is carried from frame to frame unless cfg.ocfg.reset
+// (libsac.cpp:461-466), so a caller that encodes a file frame by frame gets the reference's warm-started searches.  Callers
+// that want many frames in one GPU batch use the C ABI's sacamd_encode_frames / sacamd_decode_frames directly.
+// Decode side: the entropy decoder and the un-predictor run as ONE GPU call (sacamd_decode_frames: the decoder's three
+// predictor stages chase each other sample by sample, include/sac_amd.h); Decode() runs it, Unpredict() publishes `samples`.
+// Errors: the reference prints and continues or terminates; here every failure throws std::runtime_error with
+// sacamd_last_error() (never across the C ABI, which returns codes).
+// Not mirrored: Predictor (libsac/pred.h:9-42) -- its per-sample predict()/update() protocol is what the stage kernels
+// replace; the parity tap sacamd_debug_predict exposes its streams.
 #pragma once
 #include <cstdint>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/sac_amd.h"
 
 namespace sacamd {
+
+// common/bufio.h:7-26
+class BufIO {
+ public:
+  BufIO() : buf(1024) { Reset(); }
+  explicit BufIO(int initsize) : buf(initsize) { Reset(); }
+  void Reset() { bufpos = 0; }
+  void PutByte(int val) { if (bufpos >= buf.size()) buf.resize(buf.size() * 2); buf[bufpos++] = (uint8_t)val; }
+  int GetByte() { return bufpos >= buf.size() ? -1 : buf[bufpos++]; }
+  size_t GetBufPos() { return bufpos; }
+  std::vector<uint8_t> &GetBuf() { return buf; }
+  void assign(const uint8_t *p, size_t n) { if (buf.size() < n) buf.resize(n); std::memcpy(buf.data(), p, n); bufpos = n; }   // (not in the reference)
+ private:
+  size_t bufpos;
+  std::vector<uint8_t> buf;
+};
+
+// libsac/profile.h:61-109 (FrameStats without the Remap member: the used-value flags live on the device)
+class SacProfile {
+ public:
+  struct FrameStats { int maxbpn = 0, maxbpn_map = 0; bool enc_mapped = false; int32_t blocksize = 0, minval = 0, maxval = 0, mean = 0; };
+  struct coef { float vmin, vmax, vdef; };
+  void Init(int numcoefs) { coefs.resize(numcoefs); }
+  int LoadBaseProfile() {                                   // profile.cpp:3-89
+    float lo[SACAMD_NUM_COEFS], hi[SACAMD_NUM_COEFS], def[SACAMD_NUM_COEFS];
+    sacamd_default_profile(lo, hi, def);
+    coefs.resize(SACAMD_NUM_COEFS);
+    for (int i = 0; i < SACAMD_NUM_COEFS; i++) coefs[i] = coef{lo[i], hi[i], def[i]};
+    return 0;
+  }
+  std::size_t get_size() { return coefs.size(); }
+  void Set(int num, double vmin, double vmax, double vdef) { if (num >= 0 && num < (int)coefs.size()) coefs[num] = coef{(float)vmin, (float)vmax, (float)vdef}; }
+  float Get(std::size_t num) const { return num < coefs.size() ? coefs[num].vdef : 0.f; }
+  std::vector<coef> coefs;
+};
 
 class FrameCoder {
  public:
@@ -35,18 +80,27 @@ class FrameCoder {
     int optimize = 0, sparse_pcm = 1, zero_mean = 1, max_framelen = 20, verbose_level = 0, mt_mode = 2, adapt_block = 1;
     toptim_cfg ocfg;
   };
-  struct FrameStats { int maxbpn = 0, maxbpn_map = 0; bool enc_mapped = false; int32_t blocksize = 0, minval = 0, maxval = 0, mean = 0; };
+  using FrameStats = SacProfile::FrameStats;
+
+  // tsac_cfg -> the C ABI's flat sacamd_cfg (what INTEGRATION.md's batch driver passes to sacamd_encode_frames)
+  static sacamd_cfg to_sacamd_cfg(const tsac_cfg &cfg) {
+    sacamd_cfg c; sacamd_default_cfg(&c);
+    c.optimize = cfg.optimize; c.sparse_pcm = cfg.sparse_pcm; c.zero_mean = cfg.zero_mean; c.reset = cfg.ocfg.reset;
+    c.fraction = cfg.ocfg.fraction; c.maxnfunc = cfg.ocfg.maxnfunc; c.num_threads = cfg.ocfg.num_threads; c.sigma = cfg.ocfg.sigma;
+    c.optk = cfg.ocfg.optk; c.optimize_cost = (int)cfg.ocfg.optimize_cost; c.optimize_search = (int)cfg.ocfg.optimize_search;
+    return c;
+  }
 
   FrameCoder(int numchannels, int framesize, const tsac_cfg &sac_cfg, int device = 0)
       : numchannels_(numchannels), framesize_(framesize), numsamples_(0), cfg(sac_cfg) {
     if (sacamd_ctx_create(device, numchannels, framesize, 1, &ctx_) != 0)
       throw std::runtime_error("sacamd_ctx_create failed (no gfx950 device?)");
     samples.assign(numchannels, std::vector<int32_t>(framesize));
-    error = s2u_error = pred = samples;
-    encoded.resize(numchannels);
+    error = s2u_error = s2u_error_map = pred = samples;
+    encoded.resize(numchannels); enc_temp1.resize(numchannels); enc_temp2.resize(numchannels);
     framestats.resize(numchannels);
-    base_profile.resize(SACAMD_NUM_COEFS);
-    sacamd_default_profile(nullptr, nullptr, base_profile.data());
+    base_profile.LoadBaseProfile();
+    profile_size_bytes_ = (int)base_profile.get_size() * 4;
   }
   ~FrameCoder() { sacamd_ctx_destroy(ctx_); }
   FrameCoder(const FrameCoder &) = delete;
@@ -57,51 +111,119 @@ class FrameCoder {
   // reference semantics, one frame: Predict() = analyse + (search) + final pass + S2U
   void Predict() {
     stage_current();
-    const sacamd_cfg c = ccfg();
+    const sacamd_cfg c = to_sacamd_cfg(cfg);
     chk(sacamd_analyse(ctx_, &c));
     run_search_and_final(c);
     chk(sacamd_get_residuals(ctx_, 0, flat(error).data(), flat(pred).data(), flat(s2u_error).data(), maxbpn_));
     unflat();
   }
   void Encode() {
-    const sacamd_cfg c = ccfg();
+    const sacamd_cfg c = to_sacamd_cfg(cfg);
     chk(sacamd_encode(ctx_, &c));
+    std::vector<uint8_t> tmp;
     for (int ch = 0; ch < numchannels_; ch++) {
       int len = 0, mapped = 0, mb = 0;
       chk(sacamd_get_encoded(ctx_, 0, ch, nullptr, 0, &len, &mapped, &mb));
-      encoded[ch].resize(len);
-      chk(sacamd_get_encoded(ctx_, 0, ch, encoded[ch].data(), len, &len, &mapped, &mb));
-      framestats[ch].enc_mapped = mapped; framestats[ch].blocksize = len;
+      tmp.resize((size_t)len + 1);
+      chk(sacamd_get_encoded(ctx_, 0, ch, tmp.data(), len, &len, &mapped, &mb));
+      encoded[ch].assign(tmp.data(), (size_t)len);
+      framestats[ch].enc_mapped = mapped != 0; framestats[ch].blocksize = len;
       (mapped ? framestats[ch].maxbpn_map : framestats[ch].maxbpn) = mb;
     }
   }
-  // frame record exactly as FrameCoder::WriteEncoded (libsac.cpp:565-578)
-  void WriteEncoded(std::ostream &fout) {
-    auto put32 = [&](uint32_t v) { char b[4]; for (int i = 0; i < 4; i++) b[i] = (char)(v >> (8 * i)); fout.write(b, 4); };
-    put32((uint32_t)numsamples_);
-    for (float f : base_profile) { uint32_t ix; std::memcpy(&ix, &f, 4); put32(ix); }
-    for (int ch = 0; ch < numchannels_; ch++) {
-      const FrameStats &st = framestats[ch];
-      put32((uint32_t)st.blocksize); put32((uint32_t)st.mean); put32((uint32_t)st.minval); put32((uint32_t)st.maxval);
-      const uint16_t flag = st.enc_mapped ? (uint16_t)((1u << 9) | st.maxbpn_map) : (uint16_t)st.maxbpn;
-      char b[2] = {(char)flag, (char)(flag >> 8)};
-      fout.write(b, 2);
-      fout.write(reinterpret_cast<const char *>(encoded[ch].data()), st.blocksize);
-    }
+
+  // ---- frame record I/O, exactly FrameCoder::WriteEncoded / ReadEncoded (libsac.cpp:565-594)
+  // AudioFile-shaped target: anything with a `file` stream member (file/file.h:33)
+  template <class AF, class = decltype(std::declval<AF &>().file)>
+  void WriteEncoded(AF &fout) { write_record(fout.file); }
+  void WriteEncoded(std::ostream &fout) { write_record(fout); }
+  template <class AF, class = decltype(std::declval<AF &>().file)>
+  void ReadEncoded(AF &fin) { read_record(fin.file); }
+  void ReadEncoded(std::istream &fin) { read_record(fin); }
+
+  // FrameCoder::WriteBlockHeader / ReadBlockHeader (libsac.cpp:530-563), on any stream
+  template <class S> static int WriteBlockHeader(S &file, const std::vector<FrameStats> &framestats, int ch) {
+    uint8_t buf[18];
+    put32(buf, (uint32_t)framestats[ch].blocksize); put32(buf + 4, (uint32_t)framestats[ch].mean);
+    put32(buf + 8, (uint32_t)framestats[ch].minval); put32(buf + 12, (uint32_t)framestats[ch].maxval);
+    const uint16_t flag = framestats[ch].enc_mapped ? (uint16_t)((1u << 9) | framestats[ch].maxbpn_map) : (uint16_t)framestats[ch].maxbpn;
+    buf[16] = (uint8_t)flag; buf[17] = (uint8_t)(flag >> 8);
+    file.write(reinterpret_cast<const char *>(buf), 18);
+    return 18;
+  }
+  template <class S> static int ReadBlockHeader(S &file, std::vector<FrameStats> &framestats, int ch) {
+    uint8_t buf[18];
+    file.read(reinterpret_cast<char *>(buf), 18);
+    framestats[ch].blocksize = (int32_t)get32(buf); framestats[ch].mean = (int32_t)get32(buf + 4);
+    framestats[ch].minval = (int32_t)get32(buf + 8); framestats[ch].maxval = (int32_t)get32(buf + 12);
+    const uint16_t flag = (uint16_t)(buf[16] | (buf[17] << 8));
+    framestats[ch].enc_mapped = (flag >> 9) != 0;
+    framestats[ch].maxbpn = flag & 0xff;                     // (as the reference: the plane count lands in maxbpn for both kinds)
+    return 18;
   }
 
-  std::vector<std::vector<int32_t>> samples, error, s2u_error, pred;   // public buffers, libsac.h:54
-  std::vector<std::vector<uint8_t>> encoded;                           // BufIO payloads
+  // ---- decode side (libsac.cpp:496-505, 144-199): Decode() = entropy decode + un-predict of the record ReadEncoded took in,
+  // as one GPU call; Unpredict() hands the PCM to `samples` (mean added back, libsac.cpp:194-198)
+  void Decode() {
+    if (numsamples_ < 1 || numsamples_ > framesize_) throw std::runtime_error("FrameCoder::Decode: no frame read");
+    std::vector<uint8_t> rec;
+    auto push32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) rec.push_back((uint8_t)(v >> (8 * i))); };
+    push32((uint32_t)numsamples_);
+    for (auto &c : base_profile.coefs) { uint32_t ix; std::memcpy(&ix, &c.vdef, 4); push32(ix); }
+    for (int ch = 0; ch < numchannels_; ch++) {
+      const FrameStats &st = framestats[ch];
+      push32((uint32_t)st.blocksize); push32((uint32_t)st.mean); push32((uint32_t)st.minval); push32((uint32_t)st.maxval);
+      const uint16_t flag = st.enc_mapped ? (uint16_t)((1u << 9) | st.maxbpn) : (uint16_t)st.maxbpn;    // ReadBlockHeader keeps the planes in maxbpn
+      rec.push_back((uint8_t)flag); rec.push_back((uint8_t)(flag >> 8));
+      rec.insert(rec.end(), encoded[ch].GetBuf().begin(), encoded[ch].GetBuf().begin() + st.blocksize);
+    }
+    const long long off[2] = {0, (long long)rec.size()};
+    decoded_.assign((size_t)numchannels_ * framesize_, 0);
+    int n = 0;
+    chk(sacamd_decode_frames(ctx_, 1, framesize_, rec.data(), off, decoded_.data(), (long long)numchannels_ * framesize_, framesize_, &n, nullptr));
+    if (n != numsamples_) throw std::runtime_error("FrameCoder::Decode: sample count of the record changed");
+  }
+  void Unpredict() {
+    if (decoded_.size() != (size_t)numchannels_ * framesize_) throw std::runtime_error("FrameCoder::Unpredict before Decode");
+    for (int ch = 0; ch < numchannels_; ch++) std::memcpy(samples[ch].data(), &decoded_[(size_t)ch * framesize_], sizeof(int32_t) * (size_t)numsamples_);
+  }
+
+  std::vector<std::vector<int32_t>> samples, error, s2u_error, s2u_error_map, pred;   // public buffers, libsac.h:54
+  std::vector<BufIO> encoded, enc_temp1, enc_temp2;                                    // libsac.h:55 (the temporaries stay empty: both coder variants run on the device)
   std::vector<FrameStats> framestats;
-  std::vector<float> base_profile;                                     // 58 coefficients (vdef)
+  SacProfile base_profile;                                                             // 58 coefficients; .coefs[i].vdef is what a frame record stores
 
  private:
-  sacamd_cfg ccfg() const {
-    sacamd_cfg c; sacamd_default_cfg(&c);
-    c.optimize = cfg.optimize; c.sparse_pcm = cfg.sparse_pcm; c.zero_mean = cfg.zero_mean; c.reset = cfg.ocfg.reset;
-    c.fraction = cfg.ocfg.fraction; c.maxnfunc = cfg.ocfg.maxnfunc; c.num_threads = cfg.ocfg.num_threads; c.sigma = cfg.ocfg.sigma;
-    c.optk = cfg.ocfg.optk; c.optimize_cost = (int)cfg.ocfg.optimize_cost; c.optimize_search = (int)cfg.ocfg.optimize_search;
-    return c;
+  static void put32(uint8_t *b, uint32_t v) { for (int i = 0; i < 4; i++) b[i] = (uint8_t)(v >> (8 * i)); }
+  static uint32_t get32(const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
+  template <class S> void write_record(S &file) {
+    uint8_t buf[4];
+    put32(buf, (uint32_t)numsamples_);
+    file.write(reinterpret_cast<const char *>(buf), 4);
+    std::vector<uint8_t> profile_buf(profile_size_bytes_);
+    for (size_t i = 0; i < base_profile.coefs.size(); i++) { uint32_t ix; std::memcpy(&ix, &base_profile.coefs[i].vdef, 4); put32(&profile_buf[4 * i], ix); }   // EncodeProfile, libsac.cpp:507-518
+    file.write(reinterpret_cast<const char *>(profile_buf.data()), profile_size_bytes_);
+    for (int ch = 0; ch < numchannels_; ch++) {
+      framestats[ch].blocksize = (int32_t)encoded[ch].GetBufPos();
+      WriteBlockHeader(file, framestats, ch);
+      file.write(reinterpret_cast<const char *>(encoded[ch].GetBuf().data()), framestats[ch].blocksize);
+    }
+  }
+  template <class S> void read_record(S &file) {
+    uint8_t buf[4];
+    file.read(reinterpret_cast<char *>(buf), 4);
+    numsamples_ = (int)get32(buf);
+    std::vector<uint8_t> profile_buf(profile_size_bytes_);
+    file.read(reinterpret_cast<char *>(profile_buf.data()), profile_size_bytes_);
+    for (size_t i = 0; i < base_profile.coefs.size(); i++) { const uint32_t ix = get32(&profile_buf[4 * i]); std::memcpy(&base_profile.coefs[i].vdef, &ix, 4); }   // DecodeProfile, libsac.cpp:520-528
+    for (int ch = 0; ch < numchannels_; ch++) {
+      ReadBlockHeader(file, framestats, ch);
+      std::vector<uint8_t> &b = encoded[ch].GetBuf();
+      if (b.size() < (size_t)framestats[ch].blocksize) b.resize((size_t)framestats[ch].blocksize);
+      file.read(reinterpret_cast<char *>(b.data()), framestats[ch].blocksize);        // AudioFile::ReadData, file/file.cpp
+    }
+    if (!file) throw std::runtime_error("FrameCoder::ReadEncoded: short read");
+    decoded_.clear();
   }
   void chk(int rc) { if (rc != 0) throw std::runtime_error(std::string("sac_amd: ") + sacamd_last_error(ctx_)); }
   void stage_current() {
@@ -110,11 +232,14 @@ class FrameCoder {
     chk(sacamd_frames_upload_i32(ctx_, 1, framesize_, buf.data(), (long long)numchannels_ * numsamples_, numsamples_, &numsamples_));
   }
   void run_search_and_final(const sacamd_cfg &c) {
-    // FrameCoder::Predict (libsac.cpp:443-479): Optimize (the DDS search) -> base_profile, then the final pass.
+    // FrameCoder::Predict (libsac.cpp:443-479): Optimize (the search) -> base_profile, then the final pass.
     // base_profile is the previous frame's optimum unless --opt-reset (libsac.cpp:461-466: LoadBaseProfile only
     // `if (cfg.ocfg.reset)`; sacamd_search_frames ignores the input in that case); without optimize it is used as is.
-    if (c.optimize) chk(sacamd_search_frames(ctx_, &c, base_profile.data()));
-    chk(sacamd_predict_final(ctx_, &c, base_profile.data()));
+    std::vector<float> prof(base_profile.coefs.size());
+    for (size_t i = 0; i < prof.size(); i++) prof[i] = base_profile.coefs[i].vdef;
+    if (c.optimize) chk(sacamd_search_frames(ctx_, &c, prof.data()));
+    chk(sacamd_predict_final(ctx_, &c, prof.data()));
+    for (size_t i = 0; i < prof.size(); i++) base_profile.coefs[i].vdef = prof[i];
     int32_t st[8];
     chk(sacamd_get_stats(ctx_, st));
     for (int ch = 0; ch < numchannels_; ch++) { framestats[ch].mean = st[4 * ch]; framestats[ch].minval = st[4 * ch + 1]; framestats[ch].maxval = st[4 * ch + 2]; }
@@ -133,9 +258,10 @@ class FrameCoder {
     }
   }
   int numchannels_, framesize_, numsamples_;
+  int profile_size_bytes_ = 0;
   tsac_cfg cfg;
   sacamd_ctx *ctx_ = nullptr;
-  std::vector<int32_t> ferr_, fpred_, fs2u_;
+  std::vector<int32_t> ferr_, fpred_, fs2u_, decoded_;
   int maxbpn_[2] = {0, 0};
 };
 

@@ -92,10 +92,10 @@ struct TraceSpan { char label[64]; int kind, cls; double item_steps, flops; hipE
 
 struct sacamd_ctx {
   int device = 0, nch = 0, max_framesize = 0, max_frames = 0;
+  int num_cus = 256;          // hipDeviceProp_t::multiProcessorCount
   hipStream_t stream = nullptr;
   static constexpr int kSide = 13;                 // logical side streams: 8 OLS classes + 4 cascade launches + 1 marker
   hipStream_t cls_stream[kSide] = {};
-  hipStream_t tail_stream[kSide] = {};             // the same roles for the final pass (so that one context's tail does not sit in the stream order of another context's search)
   // `cls_stream` come from the per-device pool (DevStreams below), shared by all contexts of the device
   hipStream_t own_main = nullptr;                  // this context's main stream (the side streams are pooled)
   hipEvent_t ev_fork = nullptr, ev_join[kSide] = {}, ev_ols[kNumOlsClasses] = {};
@@ -260,7 +260,7 @@ PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_
 // context that recorded it.
 struct DevStreams {
   bool ready = false;
-  hipStream_t lo_main = nullptr, lo_cls[sacamd_ctx::kSide] = {}, lo_tail[sacamd_ctx::kSide] = {};
+  hipStream_t lo_main = nullptr, lo_cls[sacamd_ctx::kSide] = {};
   // One search at a time per device: a batch's search saturates the chip on its own, and two searches issued to the
   // pooled streams would only queue behind each other's dependency chains.  What may overlap is the search of one
   // context with the latency-bound tail of another (sacamd_encode_frames releases this before its tail).
@@ -276,16 +276,6 @@ int ensure_dev_streams(int device) {
     if (hipStreamCreate(&d.lo_main) != hipSuccess) return SACAMD_ERR_HIP;
     for (int k = 0; k < sacamd_ctx::kSide; k++)
       if (hipStreamCreate(&d.lo_cls[k]) != hipSuccess) return SACAMD_ERR_HIP;
-    // The final pass gets its own set when SACAMD_TAIL_STREAMS=1 (software-pipelined batches: bench.py --pipeline 2): its
-    // multi-second kernels would otherwise precede the next batch's search launches of the same class in stream order.
-    // Default: the same streams (a single context never overlaps its own search and tail, and fewer streams keep the
-    // hardware queues from being oversubscribed).
-    const char *e = std::getenv("SACAMD_TAIL_STREAMS");
-    const bool own_tail = e && e[0] == '1';
-    for (int k = 0; k < sacamd_ctx::kSide; k++) {
-      d.lo_tail[k] = d.lo_cls[k];
-      if (own_tail && hipStreamCreate(&d.lo_tail[k]) != hipSuccess) return SACAMD_ERR_HIP;
-    }
     d.ready = true;
   }
   return 0;
@@ -294,7 +284,7 @@ int ensure_dev_streams(int device) {
 void bind_streams(sacamd_ctx *c) {
   DevStreams &d = g_streams[c->device & 63];
   c->stream = c->own_main ? c->own_main : d.lo_main;
-  for (int k = 0; k < sacamd_ctx::kSide; k++) { c->cls_stream[k] = d.lo_cls[k]; c->tail_stream[k] = d.lo_tail[k]; }
+  for (int k = 0; k < sacamd_ctx::kSide; k++) c->cls_stream[k] = d.lo_cls[k];
 }
 
 // ------------------------------------------------------------ work-item construction
@@ -372,7 +362,7 @@ std::vector<int> xcd_interleave(const std::vector<int> &v, const std::vector<Wor
 
 // run the three predictor stages for `items`; residual -> d_err (+ d_pred when want_pred)
 int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
-  hipStream_t *side = want_pred ? c->tail_stream : c->cls_stream;
+  hipStream_t *side = c->cls_stream;
   const int count = (int)items.size();
   if (!count) return 0;
   long long tot_p = 0, tot_tab = 0;
@@ -450,15 +440,9 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // class lists, heaviest first.  Cascade items are additionally split by how long their OLS class
   // runs (group 0: one-wave classes <= 32 taps, group 1: the panel classes): a cascade launch only
   // waits for the OLS classes of its own group, so cascade work starts under the OLS tail.
-  // SACAMD_FINAL_GROUPS=1 (experiment, off by default): the final pass groups by OLS class instead, so that the cascade of a
-  // frame may start when ITS OLS kernel has ended.  Measured on 384 x 20 s: 178.0 instead of 162.1 s per step -- the panel OLS
-  // workgroups of the slow classes fill the CUs' LDS (3 x ~50 KB), the early cascade workgroups only become resident as those
-  // drain (29 s for a launch that takes 5 s on a free chip), and the 26 small launches then serialise on the four cascade
-  // streams (profiles/r03/README.md).
   constexpr int kFastOls = 3;                       // search: OLS classes [0, kFastOls) form group 0
-  static const bool fine_groups = [] { const char *e = std::getenv("SACAMD_FINAL_GROUPS"); return e && e[0] == '1'; }();
-  const int ngroups = (want_pred && fine_groups) ? kNumOlsClasses : 2;
-  auto group_of_class = [&](int ols_class) { return ngroups == 2 ? (ols_class >= kFastOls ? 1 : 0) : ols_class; };
+  constexpr int ngroups = 2;
+  auto group_of_class = [&](int ols_class) { return ols_class >= kFastOls ? 1 : 0; };
   std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][kNumOlsClasses];
   for (int i = 0; i < count; i++) {
     if (ols_lead[i] == i && !ols_skip[i]) idx_ols[items[i].ols_class].push_back(i);
@@ -524,8 +508,26 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   if (!sp_ols.a || !sp_ols.b || !sp_lms.b) return fail(c, SACAMD_ERR_HIP, "hipEventCreate failed");
   HIPCHK(c, hipEventRecord(sp_ols.a, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-  constexpr int kMark = sacamd_ctx::kSide - 1, kLmsStreams = sacamd_ctx::kSide - 1 - kNumOlsClasses;
+  constexpr int kMark = sacamd_ctx::kSide - 1;
   HIPCHK(c, hipStreamWaitEvent(side[kMark], c->ev_fork, 0));
+  // Which kernel the 33..64-tap classes (3..6) take.  The panel kernel (four waves per item, two workgroups per CU by its
+  // registers) is ~1.2-1.5x faster per sample for ONE item but needs four wave slots; what a launch costs is its slowest item,
+  // as long as every item is resident at once.  So the panel kernel goes to the longest classes first while the launch still
+  // fits the chip in one residency round (2 workgroups x CUs), the rest takes the one-wave kernel.  Round 3 ran the whole
+  // final pass on panel kernels: at 768 frames 724 panel workgroups for 512 slots -- two rounds of a 28-s kernel (56 s) -- and
+  // the search on one-wave kernels only, where a 56- / 64-tap class of a few hundred items was the last OLS kernel of its
+  // generation to end (profiles/r03/README.md, profiles/r04/README.md).  SACAMD_OLS_PANEL_SLOTS overrides the slot budget (A/B).
+  bool use_panel[kNumOlsClasses] = {};
+  {
+    static const int slots_env = [] { const char *e = std::getenv("SACAMD_OLS_PANEL_SLOTS"); return e ? std::atoi(e) : -1; }();
+    int budget = slots_env >= 0 ? slots_env : 2 * c->num_cus;
+    if (!want_pred) budget /= 4;                   // search: the chip is shared with the other classes and the cascade launches
+    for (int k = 6; k >= 3; k--) {
+      const int m = (int)idx_ols[k].size();
+      if (m > 0 && m <= budget) { use_panel[k] = true; budget -= m; }
+    }
+    use_panel[7] = true;                           // 65..96 taps: only the panel kernel exists
+  }
   for (int q = 0; q < kNumOlsClasses; q++) {
     const int k = kNumOlsClasses - 1 - q;            // heaviest class first: its items are the long pole
     if (idx_ols[k].empty()) continue;
@@ -533,14 +535,9 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     {
       double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
-      // statistics slot: the final pass runs its 33..64-tap items on the four-wave panel kernels (launch_ols), the search on the
-      // one-wave kernels: two kernel instances of one capacity class -> slots 8 + k for the former
-      // SACAMD_OLS_SMALL_PANEL=N (experiment for the next round, off by default): a 56- / 64-tap class of the SEARCH with at most N
-      // items takes the four-wave panel kernel too.  At those lengths the one-wave kernel is only 1.15-1.27x ahead in saturated
-      // throughput but 2.5x behind in per-step latency, and in the first generations such a class (a few hundred items, fewer
-      // than the chip has slots) is the last OLS kernel to finish: 6.4 s for 381 items (profiles/r03/README.md).
-      static const int small_panel = [] { const char *e = std::getenv("SACAMD_OLS_SMALL_PANEL"); return e ? std::atoi(e) : 0; }();
-      const bool panel_k = want_pred || (small_panel > 0 && (k == 5 || k == 6) && (int)idx_ols[k].size() <= small_panel);
+      // statistics slot: 33..64-tap items run either on the one-wave kernel (throughput) or on the four-wave panel kernel (lower
+      // latency per sample, four times the wave slots): two kernel instances of one capacity class -> slots 8 + k for the latter
+      const bool panel_k = use_panel[k];
       Trace tr(c, st, "ols", (panel_k && k >= 3 && k <= 6) ? 8 + k : k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
       launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, panel_k);
     }
@@ -556,12 +553,11 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // first.  Search (two groups): group 0 (items whose OLS class is one of the fast ones) takes the four cascade streams and
   // the streams of the fast OLS classes -- those kernels are exactly what the group waits for anyway; group 1 takes the
   // streams of the slow OLS classes.  Within a group the whole-CU layout (class 2: its workgroups need a drained CU) goes
-  // first, then the launches by descending work.  SACAMD_LMS_STREAMS=0 restores the round-robin over four streams.
-  static const bool spread = [] { const char *e = std::getenv("SACAMD_LMS_STREAMS"); return !(e && e[0] == '0'); }();
+  // first, then the launches by descending work.
   std::vector<int> lms_stream(lms_launches.size());
   std::vector<size_t> lms_order(lms_launches.size());
   std::iota(lms_order.begin(), lms_order.end(), (size_t)0);
-  if (spread && ngroups == 2) {
+  {
     std::vector<double> work(lms_launches.size(), 0.0);
     for (size_t q = 0; q < lms_launches.size(); q++) {
       const LmsLaunch &ll = lms_launches[q];
@@ -576,8 +572,6 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     for (int k = kFastOls; k < kNumOlsClasses; k++) pool[1].push_back(k);
     size_t used[2] = {0, 0};
     for (size_t q : lms_order) { const int g = lms_launches[q].group; lms_stream[q] = pool[g][used[g]++ % pool[g].size()]; }
-  } else {
-    for (size_t q = 0; q < lms_launches.size(); q++) lms_stream[q] = kNumOlsClasses + (int)(q % kLmsStreams);
   }
   auto launch_one = [&](size_t q) -> int {
     const LmsLaunch &ll = lms_launches[q];
@@ -648,6 +642,7 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   if (hipSetDevice(device) != hipSuccess) return SACAMD_ERR_NOGPU;
   sacamd_ctx *c = new sacamd_ctx();
   c->device = device; c->nch = nch; c->max_framesize = max_framesize; c->max_frames = max_frames;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   { const char *e = std::getenv("SACAMD_TRACE"); c->tracing = e && e[0] == '1'; }
   if (ensure_dev_streams(device) != 0) { delete c; return SACAMD_ERR_HIP; }
   // every context has its own main stream: generations of different contexts must not queue behind each other's

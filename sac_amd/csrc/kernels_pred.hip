@@ -5,6 +5,7 @@
 #include "pred_bias.h"
 #include "pred_lms.h"
 #include "pred_ols.h"
+#include "pred_ols_pack.h"
 #include "pred_tables.h"
 
 #include <atomic>
@@ -72,8 +73,12 @@ void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab) {
 }
 
 // ------------------------------------------------------------------ stage 1: OLS
+#ifndef SACAMD_EXP_PANEL_MINB
+#define SACAMD_EXP_PANEL_MINB 1
+#endif
+template <int NL, int NMAX> constexpr int ols_minb() { return (NL == 256 && NMAX <= 64) ? SACAMD_EXP_PANEL_MINB : 1; }
 template <int NL, int NMAX>
-__global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
+__global__ __launch_bounds__(NL, (ols_minb<NL, NMAX>())) void k_ols(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (idx[blockIdx.x] < 0) return;                 // padding entry of the XCD-interleaved launch list (host.hip, xcd_interleave)
   const WorkItem &it = items[idx[blockIdx.x]];
@@ -85,6 +90,44 @@ __global__ __launch_bounds__(NL) void k_ols(const WorkItem *items, const int *id
   if constexpr (NL == 64) ols_stage_reg<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
   else if constexpr (NL == 256 && NMAX > 64) ols_stage_panel2<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
   else ols_stage_panel<ExecDev<NL>, NMAX>(ex, p, self, other, it.n, out, smem, v.prof);
+}
+
+// Packed one-wave kernel for regressors up to 32 taps (pred_ols_pack.h): G = 64 / GL work-items per wave.  List position of
+// group g of workgroup w: within every block of 8 G positions workgroup w % 8 takes the positions == w % 8 (mod 8), so the
+// items of a workgroup share the residue that xcd_interleave (host.hip) gave their frames -- and with it the XCD whose L2
+// holds those frames' samples.
+template <int NMAX, int GL>
+__global__ __launch_bounds__(64, 2) void k_ols_pack(const WorkItem *items, const int *idx, int count, PcmView v, double *pbuf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = 64 / GL;
+  ExecDev<64> ex;
+  ExecDev<64>::Reg<OlsPackSlot> sl;
+  ExecDev<64>::Reg<int> kreg;
+  const int w = (int)blockIdx.x, g = (int)threadIdx.x / GL;
+  const int pos = (w >> 3) * (8 * G) + g * 8 + (w & 7);
+  const int ii = pos < count ? idx[pos] : -1;
+  const WorkItem &it = items[ii < 0 ? 0 : ii];
+  sl.v.p = &it.p;
+  sl.v.self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+  sl.v.other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
+  sl.v.out = (it.pin_kept ? v.keep : pbuf) + it.off_pin;
+  sl.v.n = ii < 0 ? 0 : it.n;
+  kreg.v = ii < 0 ? 0 : it.p.k;
+  int kk = 0;
+#pragma unroll
+  for (int q = 0; q < G; q++) { const int a = ex.lane_geti(kreg, q * GL); kk = a > kk ? a : kk; }
+  if (kk <= 0) return;                                   // nothing but padding entries
+  ols_stage_pack<ExecDev<64>, NMAX, GL>(ex, sl, kk, smem);
+}
+
+template <int NMAX, int GL>
+static void launch_ols_pack_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
+  static std::atomic<unsigned long long> done{0};
+  constexpr int G = 64 / GL;
+  const size_t bytes = ols_pack_lds_bytes<NMAX, GL>();
+  if (ensure_dyn_lds((const void *)k_ols_pack<NMAX, GL>, bytes, done) != hipSuccess) return;
+  const int blocks = ((count + 8 * G - 1) / (8 * G)) * 8;
+  hipLaunchKernelGGL((k_ols_pack<NMAX, GL>), dim3(blocks), dim3(64), bytes, s, d_items, d_idx, count, v, d_p);
 }
 
 template <int NL, int NMAX>
@@ -104,10 +147,12 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
   static_assert(kNumOlsClasses == 8 && kOlsClassMax[6] == 64 && kOlsClassMax[7] == 96, "instances below follow kOlsClassMax");
   static const int force = [] { const char *e = std::getenv("SACAMD_OLS_FINAL_PANEL"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
   const bool panel = force >= 0 ? (force == 1 && latency_bound) : latency_bound;
+  // regressors up to 32 taps: several work-items per wave (pred_ols_pack.h); SACAMD_OLS_PACK=0 selects the one-item-per-wave kernel (A/B)
+  static const bool pack = [] { const char *e = std::getenv("SACAMD_OLS_PACK"); return !(e && e[0] == '0'); }();
   switch (ols_class) {
-    case 0: launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p); break;
-    case 1: launch_ols_c<64, 24>(s, d_items, d_idx, count, v, d_p); break;
-    case 2: launch_ols_c<64, 32>(s, d_items, d_idx, count, v, d_p); break;
+    case 0: if (pack) launch_ols_pack_c<16, 16>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p); break;
+    case 1: if (pack) launch_ols_pack_c<24, 32>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 24>(s, d_items, d_idx, count, v, d_p); break;
+    case 2: if (pack) launch_ols_pack_c<32, 32>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 32>(s, d_items, d_idx, count, v, d_p); break;
     case 3: if (panel) launch_ols_c<kOlsPanelThreads, 40>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 40>(s, d_items, d_idx, count, v, d_p); break;
     case 4: if (panel) launch_ols_c<kOlsPanelThreads, 48>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 48>(s, d_items, d_idx, count, v, d_p); break;
     case 5: if (panel) launch_ols_c<kOlsPanelThreads, 56>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 56>(s, d_items, d_idx, count, v, d_p); break;
@@ -151,13 +196,22 @@ using LmsP17 = LmsClass<17, 0, 0, 0>;
 using LmsP33 = LmsClass<33, 0, 0, 0>;
 using LmsP49 = LmsClass<49, 0, 0, 0>;
 template <int CLS> struct LmsCfg;
-template <> struct LmsCfg<0> { static constexpr int ROUNDS = 1; using C = LmsA; static constexpr int NL = 256, MINB = 1; };
-template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 256, MINB = 2; };
+#ifndef SACAMD_EXP_LMS0_MINB
+#define SACAMD_EXP_LMS0_MINB 3
+#endif
+template <> struct LmsCfg<0> { static constexpr int ROUNDS = 1; using C = LmsA; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS0_MINB; };
+#ifndef SACAMD_EXP_LMS134_MINB
+#define SACAMD_EXP_LMS134_MINB 2
+#endif
+#ifndef SACAMD_EXP_LMS56_MINB
+#define SACAMD_EXP_LMS56_MINB 2
+#endif
+template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
 template <> struct LmsCfg<2> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 512, MINB = 1; };
-template <> struct LmsCfg<3> { static constexpr int ROUNDS = 1; using C = LmsD; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<4> { static constexpr int ROUNDS = 1; using C = LmsE; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<5> { static constexpr int ROUNDS = 1; using C = LmsX; static constexpr int NL = 256, MINB = 2; };
-template <> struct LmsCfg<6> { static constexpr int ROUNDS = 1; using C = LmsY; static constexpr int NL = 256, MINB = 2; };
+template <> struct LmsCfg<3> { static constexpr int ROUNDS = 1; using C = LmsD; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
+template <> struct LmsCfg<4> { static constexpr int ROUNDS = 1; using C = LmsE; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
+template <> struct LmsCfg<5> { static constexpr int ROUNDS = 1; using C = LmsX; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS56_MINB; };
+template <> struct LmsCfg<6> { static constexpr int ROUNDS = 1; using C = LmsY; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS56_MINB; };
 template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
 template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
 template <> struct LmsCfg<9> { using C = LmsK; static constexpr int NL = 256, MINB = 1, ROUNDS = 4; };
@@ -217,13 +271,11 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
 int lms_class_for(const int *vn, bool canon) {
   auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
   if (canon) {
-    static const bool old_layouts = [] { const char *e = std::getenv("SACAMD_CANON_SYSTOLIC"); return e && e[0] == '1'; }();   // A/B switch: the round-2 layouts
-    if (!old_layouts) {
-      if (canon3_fits(vn, LmsP17::c0, 2)) return 10;
-      if (canon3_fits(vn, LmsP33::c0, 2)) return 11;
-      if (canon3_fits(vn, LmsP49::c0, 2)) return 12;
-      if (canon3_fits(vn, LmsP33::c0, 4)) return 13;
-    }
+    if (canon3_fits(vn, LmsP17::c0, 2)) return 10;
+    if (canon3_fits(vn, LmsP33::c0, 2)) return 11;
+    if (canon3_fits(vn, LmsP49::c0, 2)) return 12;
+    if (canon3_fits(vn, LmsP33::c0, 4)) return 13;
+    // beyond ~7.5 k taps: the round-2 systolic layouts
     if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 7;     // one round over the lanes
     if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 8;     // two rounds
     return 9;                                                            // four rounds (profile maximum)
@@ -239,8 +291,14 @@ int lms_class_for(const int *vn, bool canon) {
 
 // register-file bound on resident workgroups per CU (237 / 256 / 256 registers, 4 / 4 / 8 waves)
 int lms_max_wg_per_cu(int lms_class) {
-  if (lms_class == 10) return 3;
-  return (lms_class == 2 || lms_class == 9 || lms_class == 12 || lms_class == 13) ? 1 : 2;
+  switch (lms_class) {
+    case 0: return LmsCfg<0>::MINB > 2 ? LmsCfg<0>::MINB : 2;
+    case 1: return LmsCfg<1>::MINB; case 3: return LmsCfg<3>::MINB; case 4: return LmsCfg<4>::MINB;
+    case 5: return LmsCfg<5>::MINB; case 6: return LmsCfg<6>::MINB;
+    case 10: return 3;
+    case 2: case 9: case 12: case 13: return 1;
+    default: return 2;
+  }
 }
 
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
@@ -417,7 +475,11 @@ void launch_dec_all(hipStream_t s, const WorkItem *d_items, const int *d_idx, in
   if (ensure_dyn_lds((const void *)k_dec_all, 160 * 1024, done) != hipSuccess) return;
   // at least 81 KB: no two blocks on one CU, whatever their roles need
   const size_t bytes = std::max({lds_cascade, any_wide ? ols_panel2_lds_bytes(96) : OlsLdsFast::bytes(64), (size_t)81 * 1024});
-  hipLaunchKernelGGL(k_dec_all, dim3(3 * m), dim3(kDecThreads), bytes, s, d_items, d_idx, m, v, d_tab, d_p, d_q, d_stats, nch, rc, d_lk_lms, d_lk_ols, d_lk_bias);
+  // cooperative launch: the runtime admits the grid only if all 3 m blocks can be resident together -- the property the stage
+  // blocks' waits rest on -- and fails the launch up front otherwise (round-3 advice), instead of leaving it to the bounded waits
+  void *args[] = {(void *)&d_items, (void *)&d_idx, (void *)&m, (void *)&v, (void *)&d_tab, (void *)&d_p, (void *)&d_q, (void *)&d_stats, (void *)&nch,
+                  (void *)&rc, (void *)&d_lk_lms, (void *)&d_lk_ols, (void *)&d_lk_bias};
+  (void)hipLaunchCooperativeKernel((const void *)k_dec_all, dim3(3 * m), dim3(kDecThreads), args, (unsigned)bytes, s);
 }
 
 // prefix[j] = number of used values in [-32768, -32768 + j - 1], j = 0 .. 65537 (Remap::isUsed: 0 is always used), one block per job

@@ -731,10 +731,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const int t = t0 + tt;
           dec_ok = sa_wait_ge(dec->prog_in, t + 1, dec->fail);
           plpc = pin_g[t];
-          if (E::is_lane0()) { pout_g[t] = plpc + pred; sa_publish(dec->prog_out, t + 1); }
+          if (ex.is_lane0()) { pout_g[t] = plpc + pred; sa_publish(dec->prog_out, t + 1); }
           dec_ok = dec_ok && sa_wait_ge(dec->prog_self, t + 1, dec->fail);
           target = (double)self[t] - plpc;
-          if (!dec_ok && E::is_lane0()) L.hs[15] = 1.0;       // a partner kernel is not there: everybody leaves after the barrier
+          if (!dec_ok && ex.is_lane0()) L.hs[15] = 1.0;       // a partner kernel is not there: everybody leaves after the barrier
         }
         // Cascade::Update(target): stage targets (cascade.h:101-112)
         double p_prefix = 0.0;
@@ -746,7 +746,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           bp[i] = target - clampd(px, lo, hi);
           p_prefix = fma(wgt, pl[i], p_prefix);
         }
-        if (E::is_lane0()) {   // hand-over to the update waves
+        if (ex.is_lane0()) {   // hand-over to the update waves
           L.hs[0] = target; L.hs[1] = ep[0]; L.hs[2] = ep[1];
           for (int i = 0; i < 5; i++) L.hs[3 + i] = pl[i];
           L.hs[8] = bp[4]; L.hs[9] = rpx;
@@ -803,7 +803,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       ex.wsync();
       ex.wave(2, [&]() {   // RLS::Predict of the NEXT step (rls.cpp:21-26): its inputs are final now
         const double rpx_next = dot_canon(L.rx, L.rw, m);
-        if (E::is_lane0w()) L.hs[10] = rpx_next;
+        if (ex.is_lane0w()) L.hs[10] = rpx_next;
       });
       // ---- wave 3: BlendExp<RunSumEMA>::Update (blend.h:31-90)
       double zm[2] = {0, 0}, maxz = 0.0;
@@ -819,7 +819,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       ex.wave(3, [&]() {
         const double w0 = ex.lane_bcast(exz_r, 192), w1 = ex.lane_bcast(exz_r, 193);
         const double inv = 1.0 / (w0 + w1);
-        if (E::is_lane0w()) { L.hs[12] = w0 * inv; L.hs[13] = w1 * inv; }
+        if (ex.is_lane0w()) { L.hs[12] = w0 * inv; L.hs[13] = w1 * inv; }
       });
       ex.wave_par(0, [&](int l) {
         // lanes 16..19: NLMS_Stream::Update scalar part (ls.h:47-48) + history push of stage l-16

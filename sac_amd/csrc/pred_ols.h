@@ -48,7 +48,10 @@ constexpr int kOlsPad = 8;
 
 // rows ip = IP .. NMAX-1 of the end-anchored back-substitution (template recursion: the register
 // array wr is only ever indexed by compile-time constants)
-constexpr int kOlsBwdChunk = 16;
+#ifndef SACAMD_EXP_BWD_CHUNK
+#define SACAMD_EXP_BWD_CHUNK 8
+#endif
+constexpr int kOlsBwdChunk = SACAMD_EXP_BWD_CHUNK;
 template <int NMAX, int S, int IP>
 struct OlsBwdRows {
   static SA_HD __attribute__((always_inline)) void run(int no, const double *lds0, const double *lb, const double *zb, double *wb, double (&wr)[NMAX]) {
@@ -550,7 +553,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
           }
         });
         ex.sync();
-        if (E::is_leader()) {
+        if (ex.is_leader()) {
           // phase 2 (wave 0): right-looking inside the panel.  The other waves wait at the barrier
           // below, so the pivots can be published as they are produced.
           ex.leader_par([&](int l) {
@@ -595,7 +598,7 @@ SA_HD void ols_stage_panel(E &ex, const ChanParam &p, const int *self, const int
         if (!ok) break;
       }
       SA_TICK(2);
-      if (ok && E::is_leader()) {
+      if (ok && ex.is_leader()) {
         // (the forward substitution was carried along by the factorisation)
         ex.leader_par([&](int l) { zreg[l] = sreg[l] * invd_mine[l]; });
         SA_TICK(3);
@@ -801,7 +804,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
           }
         });
         ex.sync();
-        if (E::is_leader()) {
+        if (ex.is_leader()) {
           // phase 2 (wave 0): right-looking inside the panel
           ex.leader_par([&](int l) {
 #pragma unroll
@@ -855,7 +858,7 @@ SA_HD void ols_stage_panel2(E &ex, const ChanParam &p, const int *self, const in
         if (!ok) break;
       }
       SA_TICK(2);
-      if (ok && E::is_leader()) {
+      if (ok && ex.is_leader()) {
         // (the forward substitution was carried along by the factorisation)
         ex.leader_par([&](int l) { zreg[l].v[0] = sreg[l].v[0] * invd_mine[l].v[0]; zreg[l].v[1] = sreg[l].v[1] * invd_mine[l].v[1]; });
         SA_TICK(3);

@@ -43,6 +43,11 @@ static std::vector<uint8_t> slurp(const std::string &p) {
 
 struct FrameRef { int file, start, length; };
 
+// communicator of a multi-rank run, reachable from the error path: a rank that fails before the gather joins it with
+// nrec = -1, so that the other ranks return from sacamd_gather_records with an error instead of waiting for it
+static sacamd_comm *g_comm = nullptr;
+static bool g_gather_entered = false;
+
 int main(int argc, char **argv) {
   try {
     sacamd_cfg cfg; sacamd_default_cfg(&cfg);
@@ -52,6 +57,7 @@ int main(int argc, char **argv) {
     bool decode_mode = false;      // --decode
     int world = 1, rank = 0, device = -1;   // --world / --rank / --device: one process per GPU
     std::string comm_id_file;
+    unsigned long long job_tag = 0; // --job-tag=N: ties the rendezvous file to this job (stale files of other runs are ignored)
     bool force_gather = false;     // --force-gather: take the communicator / gather path with one rank too (one-GPU test)
     bool header_only = false;      // --header-only: write header + MD5 of each input and stop (no device needed; tests)
     std::vector<std::string> pos;
@@ -89,6 +95,7 @@ int main(int argc, char **argv) {
       else if (a.rfind("--rank=", 0) == 0) rank = std::atoi(a.c_str() + 7);
       else if (a.rfind("--device=", 0) == 0) device = std::atoi(a.c_str() + 9);
       else if (a.rfind("--comm-id=", 0) == 0) comm_id_file = a.substr(10);
+      else if (a.rfind("--job-tag=", 0) == 0) job_tag = std::strtoull(a.c_str() + 10, nullptr, 10);
       else if (a == "--force-gather") force_gather = true;
       else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
       else pos.push_back(a);
@@ -189,21 +196,32 @@ int main(int argc, char **argv) {
     if (sacamd_ctx_create(device, nch, maxfs, max_frames, &ctx) != 0) throw std::runtime_error("no usable gfx950 device (sacamd_ctx_create failed)");
     auto chk = [&](int rc) { if (rc != 0) throw std::runtime_error(std::string("sac_amd: ") + sacamd_last_error(ctx)); };
     sacamd_comm *comm = nullptr;
-    if (use_comm) {                                    // RCCL communicator; the unique id travels through the file
-      uint8_t id[SACAMD_COMM_ID_BYTES];
+    if (use_comm) {
+      // RCCL communicator; the unique id travels through FILE = magic, world, job tag, id.  Rank 0 removes whatever a previous
+      // run left there before it writes (rename: readers never see a partial file) and again once every rank has joined;
+      // the other ranks take a file only when magic, world size and --job-tag agree -- give every job its own tag (launcher
+      // PID, time stamp) and a stale file of a crashed run can never be mistaken for this job's (round-3 advice).
+      struct IdFile { char magic[8]; uint32_t world; uint32_t pad; uint64_t tag; uint8_t id[SACAMD_COMM_ID_BYTES]; } idf;
+      static_assert(sizeof(IdFile) == 24 + SACAMD_COMM_ID_BYTES, "id file layout");
       if (rank == 0) {
-        if (sacamd_comm_unique_id(id) != 0) throw std::runtime_error("sacamd_comm_unique_id failed");
-        { std::ofstream o(comm_id_file + ".tmp", std::ios::binary); o.write((const char *)id, sizeof(id)); }
+        (void)std::remove(comm_id_file.c_str());
+        std::memset(&idf, 0, sizeof(idf));
+        std::memcpy(idf.magic, "SACAMDID", 8); idf.world = (uint32_t)world; idf.tag = job_tag;
+        if (sacamd_comm_unique_id(idf.id) != 0) throw std::runtime_error("sacamd_comm_unique_id failed");
+        { std::ofstream o(comm_id_file + ".tmp", std::ios::binary); o.write((const char *)&idf, sizeof(idf)); }
         if (std::rename((comm_id_file + ".tmp").c_str(), comm_id_file.c_str()) != 0) throw std::runtime_error("cannot write " + comm_id_file);
       } else {
         bool got = false;
         for (int tries = 0; tries < 6000 && !got; tries++) {             // up to 10 minutes
           std::ifstream f(comm_id_file, std::ios::binary);
-          if (f && f.read((char *)id, sizeof(id))) got = true; else usleep(100000);
+          if (f && f.read((char *)&idf, sizeof(idf)) && std::memcmp(idf.magic, "SACAMDID", 8) == 0 && idf.world == (uint32_t)world && idf.tag == job_tag) got = true;
+          else usleep(100000);
         }
-        if (!got) throw std::runtime_error("no RCCL unique id in " + comm_id_file);
+        if (!got) throw std::runtime_error("no RCCL unique id for this job (world " + std::to_string(world) + ", tag " + std::to_string(job_tag) + ") in " + comm_id_file);
       }
-      if (sacamd_comm_create(device, rank, world, id, &comm) != 0) throw std::runtime_error("sacamd_comm_create failed");
+      if (sacamd_comm_create(device, rank, world, idf.id, &comm) != 0) throw std::runtime_error("sacamd_comm_create failed");
+      g_comm = comm;
+      if (rank == 0) (void)std::remove(comm_id_file.c_str());            // ncclCommInitRank returned: every rank has read the id
     }
 
     // frame list: reads of maxfs samples, each cut into sub-frames (libsac.cpp:805-820)
@@ -279,10 +297,11 @@ int main(int argc, char **argv) {
       std::vector<uint8_t> all(rank == 0 ? (size_t)cap : 0);
       std::vector<long long> all_off(rank == 0 ? (size_t)total + 1 : 0);
       if (my_recs.empty()) my_recs.push_back(0);
+      g_gather_entered = true;
       const int rc = sacamd_gather_records(comm, (int)my_ids.size(), my_ids.data(), my_recs.data(), my_off.data(), total,
                                            rank == 0 ? all.data() : nullptr, rank == 0 ? cap : 0, rank == 0 ? all_off.data() : nullptr);
       if (rc != 0) throw std::runtime_error(std::string("sacamd_gather_records: ") + sacamd_comm_last_error(comm));
-      sacamd_comm_destroy(comm);
+      sacamd_comm_destroy(comm); g_comm = nullptr;
       if (rank != 0) return 0;
       for (int i = 0; i < total; i++) {
         auto &dst = payload[all_frames[i].file];
@@ -310,6 +329,10 @@ int main(int argc, char **argv) {
     return 0;
   } catch (const std::exception &e) {
     std::cerr << "sacenc: " << e.what() << "\n";
+    if (g_comm) {                  // tell the other ranks (they are in, or on their way to, the gather), then drop the communicator
+      if (!g_gather_entered) (void)sacamd_gather_records(g_comm, -1, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
+      sacamd_comm_destroy(g_comm);
+    }
     return 1;
   }
 }

@@ -115,6 +115,9 @@ struct ExecEmu {
   // inside par(): the value lane k (0..63) of lane l's own wave holds
   double wave_lane(const Reg<double> &r, int l, int k) { return r[(l & ~63) | k]; }
   int lane_geti(const Reg<int> &r, int k) { return r[k]; }
+  // groups of GL lanes: every lane takes the value lane k of ITS group holds (k uniform, < GL)
+  template <int GL> void grp_bcast(Reg<double> &dst, const Reg<double> &src, int k) { for (int l = 0; l < NL; l++) dst[l] = src[(l / GL) * GL + k]; }
+  template <int GL, class R> void grp_bcast_col(Reg<double> &dst, const R &src, int col, int k) { for (int l = 0; l < NL; l++) dst[l] = src[(l / GL) * GL + k].v[col]; }
   // every lane takes the value of lane-1 (lane 0 keeps its own): DPP wave_shr:1 on the device
   void shift_up1(Reg<double> &r) { for (int l = NL - 1; l > 0; l--) r[l] = r[l - 1]; }
   // trip count of a loop whose length differs between the waves of a workgroup: lanes < split run a iterations, the others
@@ -191,14 +194,22 @@ template <int NL>
 struct ExecDev {
   static constexpr int nl = NL;
   static constexpr bool is_device = true;
+  // Wave roles can be rotated: lane index l = (threadIdx.x + 64 * rot) mod NL, so that "wave 0" of the kernel body (the wave
+  // that runs a serial chain while the others wait at a barrier) is hardware wave (NL/64 - rot) mod NL/64.  Measured in round 4
+  // on the search cascade (rot = block index, and block/8 + block/256): no change in saturated throughput to three digits
+  // (profiles/r04/throughput_lms_rot*.txt) -- the serial chains of co-resident workgroups do not pile up on one SIMD.  Unused.
+  int base_ = 0;
+  SA_D ExecDev() {}
+  SA_D explicit ExecDev(int rot_waves) : base_(64 * rot_waves) {}
+  SA_D int tid() const { return ((int)threadIdx.x + base_) & (NL - 1); }
   template <class T> struct Reg {
     T v;
     SA_D T &operator[](int) { return v; }
     SA_D const T &operator[](int) const { return v; }
   };
-  template <class F> SA_D void par(F &&f) { f((int)threadIdx.x); }
+  template <class F> SA_D void par(F &&f) { f(tid()); }
   template <class F> SA_D void uni(F &&f) { f(); }
-  template <class F> SA_D void leader(F &&f) { if (threadIdx.x < 64) f(); }
+  template <class F> SA_D void leader(F &&f) { if (tid() < 64) f(); }
   SA_D void sync() { __syncthreads(); }
   template <int K, class R> SA_D void wave_sum(R &r) {
     constexpr int W = NL < 64 ? NL : 64;
@@ -240,6 +251,14 @@ struct ExecDev {
   }
   template <class T> SA_D T lane_get(const Reg<T> &r, int k) { return __shfl(r.v, k, 64); }
   SA_D int lane_geti(const Reg<int> &r, int k) { return __builtin_amdgcn_readlane(r.v, k); }
+  // lane k of the calling lane's group of GL lanes (one wave): ds_bpermute_b32 (the LDS crossbar, no memory access)
+  template <int GL> static SA_D double grp_pick(double x, int k) {
+    const int src = (((int)threadIdx.x & 63 & ~(GL - 1)) + k) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+  }
+  template <int GL> SA_D void grp_bcast(Reg<double> &dst, const Reg<double> &src, int k) { dst.v = grp_pick<GL>(src.v, k); }
+  template <int GL, class R> SA_D void grp_bcast_col(Reg<double> &dst, const R &src, int col, int k) { dst.v = grp_pick<GL>(src.v.v[col], k); }
   SA_D void shift_up1(Reg<double> &r) {
     int lo = __double2loint(r.v), hi = __double2hiint(r.v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
@@ -247,15 +266,15 @@ struct ExecDev {
     r.v = __hiloint2double(hi, lo);
   }
   static SA_D int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-  SA_D int wave_hops(int split, int a, int b) { return __builtin_amdgcn_readfirstlane((int)threadIdx.x < split ? a : b); }
-  template <class F> SA_D void lane0(F &&f) { if (threadIdx.x == 0) f(); }
+  SA_D int wave_hops(int split, int a, int b) { return __builtin_amdgcn_readfirstlane(tid() < split ? a : b); }
+  template <class F> SA_D void lane0(F &&f) { if (tid() == 0) f(); }
   static SA_D unsigned long long clock() { return __builtin_readcyclecounter(); }
-  static SA_D bool is_lane0() { return threadIdx.x == 0; }
-  static SA_D bool is_leader() { return threadIdx.x < 64; }
+  SA_D bool is_lane0() const { return tid() == 0; }
+  SA_D bool is_leader() const { return tid() < 64; }
   static SA_D bool is_lane0w() { return (threadIdx.x & 63) == 0; }
-  template <class F> SA_D void leader_par(F &&f) { if (threadIdx.x < 64) f((int)threadIdx.x); }
-  template <class F> SA_D void wave(int w, F &&f) { if ((int)(threadIdx.x >> 6) == w) f(); }
-  template <class F> SA_D void wave_par(int w, F &&f) { if ((int)(threadIdx.x >> 6) == w) f((int)threadIdx.x); }
+  template <class F> SA_D void leader_par(F &&f) { if (tid() < 64) f(tid()); }
+  template <class F> SA_D void wave(int w, F &&f) { if ((tid() >> 6) == w) f(); }
+  template <class F> SA_D void wave_par(int w, F &&f) { if ((tid() >> 6) == w) f(tid()); }
   SA_D void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
   // value of lane k (k uniform across the wave) -> scalar broadcast via v_readlane_b32
   SA_D double lane_bcast(const Reg<double> &r, int k) {
@@ -283,7 +302,7 @@ struct ExecDev {
 #pragma unroll
     for (int d = W / 2; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
     if (NL > 64) {
-      const int w = threadIdx.x >> 6;
+      const int w = tid() >> 6;
       if ((threadIdx.x & 63) == 0) scratch[w] = v;
       __syncthreads();
       double s = scratch[0];

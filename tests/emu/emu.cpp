@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../../sac_amd/csrc/pred_ols.h"
+#include "../../sac_amd/csrc/pred_ols_pack.h"
 #include "../../sac_amd/csrc/pred_lms.h"
 #include "../../sac_amd/csrc/pred_bias.h"
 #include "../../sac_amd/csrc/pred_tables.h"
@@ -101,6 +102,43 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     else run_lms<LmsClass<16, 8, 4, 2>, 512>(p, sp, tab.data(), self, n, ps);   // as the launcher: 512 lanes
     std::vector<double> tables(kBiasSlabDoubles);
     bias_stage(p, self, n, ps, stats[3 * ch_self + 2], err + (size_t)ch_self * n, pred ? pred + (size_t)ch_self * n : nullptr, tables.data());
+  }
+  return 0;
+}
+
+// Packed OLS stage (pred_ols_pack.h): `count` mono/stereo-slot work-items, G = 64 / GL per emulated wave, in list order.
+// Item i: samples_i planar [nch_i][total_i] (mean-removed), stats_i [nch_i][3], coefs_i [58], slot_i (0 / 1), n_i samples from 0;
+// output plpc_i [n_i].  cls: 0 = <16, 16 lanes>, 1 = <24, 32 lanes>, 2 = <32, 32 lanes>.  Returns 0, or -1 when an item does not fit.
+API int emu_ols_pack(int cls, int count, const int *nch, const int *total, const int32_t *const *samples, const int32_t *const *stats,
+                     const float *const *coefs, const int *slot, const int *n, int optimize, int optk, double *const *plpc) {
+  std::vector<ChanParam> cps(count);
+  std::vector<const int *> selfs(count), others(count);
+  const int nmaxc = cls == 0 ? 16 : cls == 1 ? 24 : 32;
+  for (int i = 0; i < count; i++) {
+    FrameStatsD st[2] = {};
+    for (int ch = 0; ch < nch[i]; ch++) { st[ch].minval = stats[i][3 * ch]; st[ch].maxval = stats[i][3 * ch + 1]; st[ch].mean = stats[i][3 * ch + 2]; st[ch].numsamples = total[i]; }
+    ChanParam cp[2]; int ch_ref = 0;
+    map_profile(coefs[i], optimize != 0, optk, nch[i], st, cp, &ch_ref);
+    const int ch_self = (nch[i] == 2) ? (slot[i] == 0 ? ch_ref : 1 - ch_ref) : 0;
+    const int ch_other = (nch[i] == 2) ? 1 - ch_self : 0;
+    cps[i] = cp[slot[i]];
+    if (cps[i].n_ols > nmaxc) return -1;
+    selfs[i] = samples[i] + (size_t)ch_self * total[i];
+    others[i] = samples[i] + (size_t)ch_other * total[i];
+  }
+  const int GL = cls == 0 ? 16 : 32, G = 64 / GL;
+  for (int b = 0; b < count; b += G) {
+    ExecEmu<64> ex;
+    ExecEmu<64>::Reg<OlsPackSlot> sl;
+    for (int l = 0; l < 64; l++) {
+      const int i = b + l / GL;
+      if (i < count) sl[l] = OlsPackSlot{&cps[i], selfs[i], others[i], plpc[i], n[i]};
+      else sl[l] = OlsPackSlot{&cps[b], selfs[b], others[b], nullptr, 0};
+    }
+    const int kk = cps[b].k;
+    if (cls == 0) { std::vector<char> lds(ols_pack_lds_bytes<16, 16>(), (char)0xFF); ols_stage_pack<ExecEmu<64>, 16, 16>(ex, sl, kk, lds.data()); }
+    else if (cls == 1) { std::vector<char> lds(ols_pack_lds_bytes<24, 32>(), (char)0xFF); ols_stage_pack<ExecEmu<64>, 24, 32>(ex, sl, kk, lds.data()); }
+    else { std::vector<char> lds(ols_pack_lds_bytes<32, 32>(), (char)0xFF); ols_stage_pack<ExecEmu<64>, 32, 32>(ex, sl, kk, lds.data()); }
   }
   return 0;
 }

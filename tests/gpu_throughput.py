@@ -17,7 +17,9 @@ steps = 4000
 cases = [(16, 0, None), (32, 0, None), (32, 32, None), (16, 0, (3383, 1168, 614, 273))]
 counts = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "256,1024,2048,4096,8192".split(","))]
 if len(sys.argv) > 2:      # OLS regressor lengths, e.g. 16,24,32,40,48,56,64
-    cases = [(min(int(v), 32), max(int(v) - 32, 0), None) for v in sys.argv[2].split(",")]
+    cases = [(min(int(v), 32), max(int(v) - 32, 0), None) for v in sys.argv[2].split(",") if v]
+if len(sys.argv) > 3:      # cascade stage lengths, e.g. "1280,256,32,4;1500,2500,900,400" (with 16 OLS taps)
+    cases += [(16, 0, tuple(int(x) for x in t.split(","))) for t in sys.argv[3].split(";")]
 for nA, nM0, taps in cases:
     g = P[:, 2].copy(); g[24] = nA; g[9] = nM0
     if taps: g[28], g[29], g[30], g[37] = taps

@@ -239,12 +239,29 @@ try:
     raise AssertionError("duplicate frame id accepted")
 except api.SacAmdError:
     pass
-# receive buffer too small on rank 0: rank 0 reports it after serving the peers
+# receive buffer too small on rank 0: its capacity travels in the first all-gather, EVERY rank returns the error before a
+# payload moves (round 3: rank 0 alone, after serving the peers)
 try:
-    r = api.gather_records_via(tr, [rank], [b"z" * 100], 2, cap=150)
-    assert rank != 0 and r is None
+    api.gather_records_via(tr, [rank], [b"z" * 100], 2, cap=150)
+    raise AssertionError("too small a receive buffer accepted")
 except api.SacAmdError:
-    assert rank == 0
+    pass
+# a rank whose own work failed joins the gather with nrec = -1: nobody waits for its records, every rank gets an error
+lib = api.load_library()
+import ctypes
+import numpy as np
+ids = np.array([rank], np.int32); blob = np.frombuffer(b"q" * 10, np.uint8).copy(); off = np.array([0, 10], np.int64)
+out = np.zeros(64, np.uint8); out_off = np.zeros(3, np.int64)
+rc = lib.sacamd_gather_records_via(ctypes.byref(tr), -1 if rank == 1 else 1, api._vp(ids), api._vp(blob), api._vp(off), 2,
+                                   api._vp(out) if rank == 0 else None, ctypes.c_longlong(64 if rank == 0 else 0), api._vp(out_off) if rank == 0 else None)
+assert rc != 0, rc
+# bad arguments on rank 0 only (no out_off): both ranks return an error together
+rc = lib.sacamd_gather_records_via(ctypes.byref(tr), 1, api._vp(ids), api._vp(blob), api._vp(off), 2, api._vp(out) if rank == 0 else None,
+                                   ctypes.c_longlong(64 if rank == 0 else 0), None)
+assert rc != 0, rc
+# ... and the transport is still usable afterwards
+out2 = api.gather_records_via(tr, [rank], [bytes([rank]) * 5], 2)
+assert (out2 == [b"\x00" * 5, b"\x01" * 5]) if rank == 0 else out2 is None
 if rank == 0:
     print("GATHER_OK")
 dist.barrier(); dist.destroy_process_group()
@@ -422,6 +439,57 @@ def test_register_resident_ols_kernel_body_vs_oracle(emu, orc, nA, nM0, opt):
     pd, ol, om, oe = orc.predict_trace(smp, stats, g, 0, n, opt)
     assert np.array_equal(plpc.view(np.uint64), ol.view(np.uint64))
     assert np.array_equal(err, oe) or opt          # search evaluations: free-order cascade sums (tolerance elsewhere)
+
+
+def _pack_items(orc, spec, n_of, seed0):
+    """work-items for emu_ols_pack: spec = [(nch, slot, nA or nB.., extra)], returns the ctypes argument arrays and the oracle's p_lpc"""
+    from sac_amd.synth import synth_pcm
+    items = []
+    for i, (nch, slot, n_self, n_other) in enumerate(spec):
+        n = n_of(i)
+        raw = synth_pcm(n, nch, seed0 + i, 8000)
+        g = np.ascontiguousarray(orc.profile()[:, 2].copy(), np.float32)
+        if slot == 0:
+            g[24], g[9] = n_self, n_other                     # ch0: nA own samples + nM0 of the other channel
+        else:
+            g[25] = n_self; g[26] = min(n_other, 32); g[27] = max(n_other - 32, 0)    # ch1: nB + nS0 + nS1
+        g[0] = orc.profile()[0, 0] + (orc.profile()[0, 1] - orc.profile()[0, 0]) * (0.2 + 0.05 * (i % 9))     # distinct regularisers / forgetting factors
+        g[28], g[29], g[30], g[37] = 64, 32, 16, 4
+        smp, stats = center_frame(raw)
+        items.append((nch, slot, n, np.ascontiguousarray(smp, np.int32), np.ascontiguousarray(stats, np.int32), g))
+    return items
+
+
+@pytest.mark.parametrize("cls,opt", [(0, 1), (0, 0), (1, 1), (1, 0), (2, 1), (2, 0)])
+def test_packed_ols_kernel_body_vs_oracle(emu, orc, cls, opt):
+    """pred_ols_pack.h: four (16 lanes each) resp. two (32 lanes each) work-items per wave -- regressor lengths, frame lengths,
+    channel slots and OLS coefficients differ inside a wave, one group left empty -- p_lpc of every item bit-identical to the
+    oracle (itself pinned to the genuine reference), k = 1 (final pass) and k = 4 (search)."""
+    nmax = (16, 24, 32)[cls]
+    lens = [nmax, nmax - 1, 5, nmax - 7, 8, nmax - 3, 4, 9, nmax]           # last wave only partly filled
+    spec = []
+    for i, ln in enumerate(lens):
+        if i % 3 == 2 and ln >= 6:
+            spec.append((2, 1, ln // 2, ln - ln // 2))           # stereo, slot 1: own + other-channel samples
+        elif i % 3 == 1 and ln >= 6:
+            spec.append((2, 0, ln - 2, 2))                       # stereo, slot 0 with nM0 = 2
+        else:
+            spec.append((1, 0, ln, 0))
+    items = _pack_items(orc, spec, lambda i: 150 + 17 * (i % 4), 700 + 10 * cls)
+    cnt = len(items)
+    IP = ctypes.POINTER(ctypes.c_int32); FP = ctypes.POINTER(ctypes.c_float); DP = ctypes.POINTER(ctypes.c_double)
+    outs = [np.zeros(it[2]) for it in items]
+    arr = lambda T, vals: (T * cnt)(*vals)
+    rc = emu.emu_ols_pack(cls, cnt, arr(ctypes.c_int, [it[0] for it in items]), arr(ctypes.c_int, [it[3].shape[1] for it in items]),
+                          arr(IP, [it[3].ctypes.data_as(IP) for it in items]), arr(IP, [it[4].ctypes.data_as(IP) for it in items]),
+                          arr(FP, [it[5].ctypes.data_as(FP) for it in items]), arr(ctypes.c_int, [it[1] for it in items]),
+                          arr(ctypes.c_int, [it[2] for it in items]), opt, 4, arr(DP, [o.ctypes.data_as(DP) for o in outs]))
+    assert rc == 0
+    for i, it in enumerate(items):
+        nch, slot, n, smp, stats, g = it
+        pd, ol, om, oe = orc.predict_trace(smp, stats, g, 0, n, opt)
+        # file channel of predictor slot `slot`: ch_ref = 0 for these profiles (coefficient 27 >= 0)
+        assert np.array_equal(outs[i].view(np.uint64), ol[slot if nch == 2 else 0].view(np.uint64)), (i, spec[i])
 
 
 def test_decoder_body_emulated_inverts_the_golden_streams(emu, orc, golden):
