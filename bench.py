@@ -33,7 +33,6 @@ import json
 import os
 import signal
 import sys
-import threading
 import time
 
 T_PROC_START = time.time()
@@ -271,9 +270,6 @@ def main():
                          "a latency-bound tail (final pass + coder) that grows 1.4x for twice the frames, so throughput grows with the batch")
     ap.add_argument("--seconds", type=float, default=float(os.environ.get("SAC_BENCH_SECONDS", 20.0)), help="frame length")
     ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("SAC_BENCH_PIPELINE", 1)),
-                    help="contexts per GPU over which consecutive steps are software-pipelined: step i+1's search runs "
-                         "under step i's latency-bound final pass + coder")
     ap.add_argument("--mode", default="high")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="decode every record of the last step with the CPU checker afterwards (slow)")
@@ -281,6 +277,7 @@ def main():
                     help="after the timed region decode this many seeded-random frame records of the last step with the CPU reference "
                          "decoder (oracle/_ref, else the oracle) and compare with the input PCM; 0 = off")
     ap.add_argument("--no-all-cores", action="store_true", help="skip the all-host-cores CPU figure")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-batch (64 frames) and single-frame measurements behind the timed region")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("SAC_BENCH_SCALING", "weak"),
                     help="weak: --frames frames per GPU; strong: one corpus of --frames frames split over the ranks by sacamd_assign_frames")
     ap.add_argument("--gather", choices=("rccl", "torch"), default=os.environ.get("SAC_BENCH_GATHER", "rccl"),
@@ -382,15 +379,10 @@ def main():
     torch.cuda.synchronize()
     t_h2d = time.perf_counter() - t_h2d
     cfg = api.make_cfg(args.mode, num_threads=args.dds_n, reset=1)
-    # The kernels are latency-bound recurrences (one wave or one workgroup per frame x candidate x
-    # channel).  A batch ends with a latency-bound tail (final pass: one work-item per frame x channel,
-    # then the range coder) that leaves most of the chip idle, so consecutive steps are software-pipelined
-    # over --pipeline contexts (each with its own device buffers): step i runs on context i % depth, and while
-    # one context is in its tail the next step's search fills the chip.  Every context stages the whole
-    # batch; the library lets one search run at a time per device.  Default depth 1: measured on MI355X the overlap does
-    # not pay (a dependent fp64 chain already keeps its SIMD's issue port ~70 % busy).
-    depth = max(1, args.pipeline)
-    ctxs = [api.Context(2, max(n, 16), max(nloc, 1), device=local_rank) for _ in range(depth)]
+    # One context holds the whole batch of this rank.  (Rounds 2-3 could software-pipeline consecutive steps over several
+    # contexts; measured as a loss every time -- DESIGN.md 9 -- and removed in round 4.)
+    depth = 1
+    ctxs = [api.Context(2, max(n, 16), max(nloc, 1), device=local_rank)]
     frame_off = np.arange(nloc, dtype=np.int64) * n
     nsamp = np.full(nloc, n, np.int32)
     groups = [(c, frame_off, nsamp) for c in ctxs]     # (kept name: the statistics helpers below iterate over it)
@@ -444,41 +436,11 @@ def main():
     for ctx in ctxs:
         ctx.eval_stats(reset=True)
 
-    # ---- timed region: steps pipelined over the contexts, their number decided against the wall budget
+    # ---- timed region: as many full steps as fit the wall budget (at least one, at most --steps), decided after step 0
     budget = args.budget_s if args.budget_s > 0 else float("inf")
     steps_max = max(1, args.steps)
-    lock = threading.Condition()
-    # planned: number of steps that will be run; the first `depth` are committed, the rest is decided (on all
-    # ranks alike) when step 0 has completed and its duration is known
-    state = {"planned": None, "done": [None] * steps_max, "started": [False] * steps_max, "error": None}
-
-    def worker(d):
-        try:
-            for step in range(d, steps_max, depth):
-                with lock:
-                    while step >= depth and state["planned"] is None and state["error"] is None:
-                        lock.wait()
-                    if state["error"] is not None or (state["planned"] is not None and step >= state["planned"]):
-                        return
-                    # keep the steps in order: wait until the previous step has begun (its search holds the device's
-                    # search lock; this step's search then queues behind it)
-                    while step > 0 and not state["started"][step - 1] and state["error"] is None:
-                        lock.wait()
-                if step > 0:
-                    prev = ctxs[(step - 1) % depth]
-                    while prev.progress()[0] < 1 and state["done"][step - 1] is None and state["error"] is None:
-                        time.sleep(0.005)
-                with lock:
-                    state["started"][step] = True
-                    lock.notify_all()
-                recs = run_step(d)
-                with lock:
-                    state["done"][step] = (recs, time.perf_counter())
-                    lock.notify_all()
-        except BaseException as e:       # surface worker failures in the main thread
-            with lock:
-                state["error"] = e
-                lock.notify_all()
+    # the measurements behind the timed region (rank 0, N = 1: small-batch and single-frame figures) get their share of the budget
+    extras_s = 0.0 if (world > 1 or args.no_extras) else 150.0
 
     samples_per_step = total_frames * n * 2
     latest = {"line": None}
@@ -501,7 +463,7 @@ def main():
             "config": {"workload": f"{args.frames} frames{'/GPU' if args.scaling == 'weak' else ' in all, split over the GPUs'} x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
                                    f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
                        "frames_per_gpu": nloc, "total_frames": total_frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
-                       "pipeline_depth": depth, "rccl_ranks": world if dist is not None else 1,
+                       "rccl_ranks": world if dist is not None else 1,
                        "record_gather": gather_kind, "record_gather_note": gather_note,
                        "parallelism": f"frames sharded over {world} GPU(s), record gather to rank 0 in frame order",
                        "warmup_batch": "min(8, frames of the group) frames x 2 s per group (code-object load only)",
@@ -510,13 +472,17 @@ def main():
             "complete": bool(final),
         }
         out["h2d"] = {"ms": t_h2d * 1e3, "bytes": int(il.nbytes), "in_timed_region": False,
-                      "note": "inputs are resident in HBM when the timed region starts; the one-off pageable-host copy of the step's PCM is reported here"}
+                      "value_incl_h2d": samples_per_step * nsteps / (dt + nsteps * t_h2d) / 1e6,
+                      "note": "`value` follows the bench contract (inputs resident in HBM when the timed region starts); value_incl_h2d adds one "
+                              "host-to-device copy of the step's PCM (pageable host memory, measured once before the region) to every step: the PCIe-inclusive rate"}
         if cb is not None:
             if cb_all is not None:
                 cb["all_cores"] = cb_all
             cb["threads8"] = _CPU_THREADS_N    # (key name kept; "cores" inside says how many threads: --dds-n)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            if _CPU_THREADS_N is not None:       # like for like: the reference's own threading for --opt-cfg=dds,N
+                out["speedup_vs_reference_threads"] = value / _CPU_THREADS_N["value"]
             out["cpu_baseline"]["same_record_as_gpu"] = bool(last_recs and last_recs[0] == cb_record)
         return out
 
@@ -587,39 +553,26 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker, args=(d,), daemon=True) for d in range(depth)]
-    for t in threads:
-        t.start()
     allrecs = last_recs = None
     nsteps = 0
+    planned = steps_max
     step = 0
     while True:
-        with lock:
-            while state["done"][step] is None and state["error"] is None:
-                lock.wait()
-            if state["error"] is not None:
-                raise state["error"]
-        recs, t_done = state["done"][step]
-        state["done"][step] = (None, t_done)      # drop the payload
+        recs = run_step(0)
+        t_done = time.perf_counter()
         if step == 0:
-            # how many steps fit the budget: step 0 took t_first from start to end; in steady state a step costs
-            # about its search time (tails hidden) -- estimated at 70 % of t_first when pipelined
             t_first = t_done - t0
-            per_step = t_first * (0.7 if depth > 1 else 1.0)
-            left = budget - (time.time() - t_start) - 25.0 - (t_first * 0.5 if depth > 1 else 0.0)
-            planned = 1 + max(0, int(left // (per_step * 1.05))) if budget != float("inf") else steps_max
-            planned = max(min(planned, steps_max), min(depth, steps_max))
+            left = budget - (time.time() - t_start) - 25.0 - extras_s
+            planned = 1 + max(0, int(left // (t_first * 1.05))) if budget != float("inf") else steps_max
+            planned = max(min(planned, steps_max), 1)
             if dist is not None:                 # all ranks plan the same number of steps
                 pl = torch.tensor([planned], dtype=torch.int32, device=device)
                 dist.all_reduce(pl, op=dist.ReduceOp.MIN)
-                planned = max(int(pl.item()), min(depth, steps_max))
-            with lock:
-                state["planned"] = planned
-                lock.notify_all()
+                planned = max(int(pl.item()), 1)
         allrecs = gather(recs) if dist is not None else recs
         last_recs = recs
         nsteps = step + 1
-        if nsteps >= state["planned"]:
+        if nsteps >= planned:
             break
         if rank == 0:        # cumulative line (the timed region is still open: no barrier here)
             dt_now = time.perf_counter() - t0
@@ -629,8 +582,6 @@ def main():
         step += 1
     barrier()
     dt = time.perf_counter() - t0
-    for t in threads:
-        t.join()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -652,6 +603,26 @@ def main():
             out["verified_lossless"] = bool(all(oks))
             out["verified_frames"] = pick
             out["verified_with"] = "oracle/_ref decoder (genuine reference objects)" if ref_available() else "oracle restatement"
+        if extras_s > 0 and not args.no_extras:
+            # ---- outside the timed region: the same path on the SURVEY 8(d) corpus size (64 frames) and on ONE frame -- what a
+            # caller with little material gets (the step above is throughput at a batch that fills the chip)
+            try:
+                def timed(k):
+                    ctx = ctxs[0]
+                    ctx.attach_s16_device(d_pcm.data_ptr(), frame_off[:k], nsamp[:k], framesize)
+                    torch.cuda.synchronize(); ta = time.perf_counter()
+                    ctx.analyse(cfg); ctx.encode_frames(cfg)
+                    torch.cuda.synchronize(); return time.perf_counter() - ta
+                k64 = min(64, nloc)
+                if time.time() - t_start < budget - 110:
+                    s64 = timed(k64)
+                    out["small_batch"] = {"frames": k64, "MSamples_s": k64 * n * 2 / s64 / 1e6, "s_per_step": s64}
+                if time.time() - t_start < budget - 70:
+                    s1 = timed(1)
+                    out["single_frame_s"] = s1
+                    out["single_frame_MSamples_s"] = n * 2 / s1 / 1e6
+            except Exception as e:
+                out["small_batch_error"] = repr(e)
         _flush_c_stdio()                       # (the reference objects print from C++ at load time: keep that ahead of the line)
         print(json.dumps(out), flush=True)
     if comm is not None:
