@@ -502,7 +502,11 @@ def main():
         # dominant kernel: the instance with the largest total launch time within the stage that spans most of the
         # step (launches of different classes overlap, so their times do not add up; the OLS stage span is the longest)
         fam = "k_ols" if kt["ols"]["ms"] >= max(kt["lms"]["ms"], kt["coder"]["ms"]) else ("k_lms" if kt["lms"]["ms"] >= kt["coder"]["ms"] else "k_coder")
-        dom = max((k for k in cands if k.startswith(fam)), key=lambda k: cands[k][0])
+        # (instances that carry less than 5 % of the family's item-steps are left out: the whole-CU cascade layout k_lms<2> holds
+        #  ~1 % of the cascade work and its launch time is mostly its workgroups WAITING for a drained CU)
+        fam_steps = sum(v[3] for k, v in cands.items() if k.startswith(fam))
+        pool = [k for k in cands if k.startswith(fam) and (fam_steps <= 0 or cands[k][3] >= 0.05 * fam_steps)] or [k for k in cands if k.startswith(fam)]
+        dom = max(pool, key=lambda k: cands[k][0])
         dms, dlaunch, dbytes, disteps, dflops = cands[dom]
         # HBM traffic per item-step of that kernel from the newest committed PMC pass (profiles/rNN/pmc_hbm.json), if present
         traffic = None
