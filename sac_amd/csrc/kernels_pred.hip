@@ -73,6 +73,7 @@ void launch_tables(hipStream_t s, WorkItem *d_items, int count, double *d_tab) {
 }
 
 // ------------------------------------------------------------------ stage 1: OLS
+// (build-time knob, tools/build_variant.sh: the panel kernels at three workgroups per CU by launch bounds were measured as a loss)
 #ifndef SACAMD_EXP_PANEL_MINB
 #define SACAMD_EXP_PANEL_MINB 1
 #endif
@@ -196,6 +197,10 @@ using LmsP17 = LmsClass<17, 0, 0, 0>;
 using LmsP33 = LmsClass<33, 0, 0, 0>;
 using LmsP49 = LmsClass<49, 0, 0, 0>;
 template <int CLS> struct LmsCfg;
+// Residency (workgroups per CU the compiler must make room for: __launch_bounds__) of the search cascade layouts.  Build-time knobs
+// of tools/build_variant.sh (A/B libraries); the defaults are the measured optimum (profiles/r04/README.md 2): three per CU for the
+// 15-slot layout (168 VGPRs, 42 spilled: 179 -> 230 M item-steps/s), two for the others (three per CU there spills 130-230 registers and
+// loses 2-3x).
 #ifndef SACAMD_EXP_LMS0_MINB
 #define SACAMD_EXP_LMS0_MINB 3
 #endif

@@ -48,6 +48,7 @@ constexpr int kOlsPad = 8;
 
 // rows ip = IP .. NMAX-1 of the end-anchored back-substitution (template recursion: the register
 // array wr is only ever indexed by compile-time constants)
+// (build-time knob, tools/build_variant.sh; 16 in rounds 1-3.  8 frees 14-32 VGPRs in the one-wave kernels at the same throughput)
 #ifndef SACAMD_EXP_BWD_CHUNK
 #define SACAMD_EXP_BWD_CHUNK 8
 #endif
