@@ -218,7 +218,13 @@ template <class E, int NMAX>
 SA_HD void ols_stage_reg(E &ex, const ChanParam &p, const int *self, const int *other, int n,
                          double *p_out, char *lds_base, unsigned long long *prof = nullptr, const DecLink *dec = nullptr) {
   static_assert(E::nl == 64 && NMAX <= 64 && NMAX % 4 == 0, "one-wave path");
-  constexpr bool MREG = NMAX <= 32;         // covariance rows in registers (else: packed triangle in LDS)
+// Round 4: the covariance rows are register resident for EVERY one-wave class (rounds 1-3: up to 32 taps, a packed triangle in LDS
+// above).  The LDS path's address arithmetic cost more registers than the rows themselves (64 taps: 322 instead of 330 registers) and
+// a fifth of the time: 116 -> 143, 86 -> 106, 50 -> 62, 29 -> 35 M item-steps/s at 40 / 48 / 56 / 64 taps (profiles/r04/throughput_mreg_*.txt).
+#ifndef SACAMD_EXP_MREG_MAX
+#define SACAMD_EXP_MREG_MAX 64
+#endif
+  constexpr bool MREG = NMAX <= SACAMD_EXP_MREG_MAX;         // covariance rows in registers (else: packed triangle in LDS)
   constexpr int S = NMAX + kOlsPad;
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;
 #define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
