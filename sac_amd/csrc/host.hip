@@ -520,7 +520,9 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   bool use_panel[kNumOlsClasses] = {};
   {
     static const int slots_env = [] { const char *e = std::getenv("SACAMD_OLS_PANEL_SLOTS"); return e ? std::atoi(e) : -1; }();
-    int budget = slots_env >= 0 ? slots_env : 2 * c->num_cus;
+    // (13/20 of the slots: with every slot taken -- 508 panel workgroups for 512 -- a few of them wait for a whole kernel generation of
+    //  the others, and the one-wave classes starve: 233.7 s per step; at 330 of 512: 222.2 s, profiles/r04/README.md)
+    int budget = slots_env >= 0 ? slots_env : (2 * c->num_cus * 13) / 20;
     if (!want_pred) budget /= 4;                   // search: the chip is shared with the other classes and the cascade launches
     for (int k = 6; k >= 3; k--) {
       const int m = (int)idx_ols[k].size();
@@ -528,9 +530,21 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     }
     use_panel[7] = true;                           // 65..96 taps: only the panel kernel exists
   }
+  // Final pass: the panel launches go first and get a head start.  A panel workgroup needs a wave slot on all four SIMDs of a CU;
+  // once one-wave waves of the other classes sit on the SIMDs, panel workgroups wait for whole CUs to drain (the 56-tap class took
+  // 72.7 s instead of 43 s when the faster one-wave kernels of round 4 were submitted at the same moment).  So the one-wave
+  // classes are submitted a few milliseconds after the panel kernels have started, when every panel workgroup is resident.
+  static const int stagger_us = [] { const char *e = std::getenv("SACAMD_PANEL_STAGGER_US"); return e ? std::atoi(e) : 5000; }();
+  bool panel_launched = false, staggered = false;
   for (int q = 0; q < kNumOlsClasses; q++) {
     const int k = kNumOlsClasses - 1 - q;            // heaviest class first: its items are the long pole
     if (idx_ols[k].empty()) continue;
+    if (want_pred && stagger_us > 0 && panel_launched && !staggered && !use_panel[k]) {
+      HIPCHK(c, hipEventSynchronize(c->ev_fork));      // the panel kernels' only dependency
+      usleep(stagger_us);
+      staggered = true;
+    }
+    if (use_panel[k]) panel_launched = true;
     hipStream_t st = side[k];
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     {
