@@ -9,6 +9,7 @@ from sac_amd.synth import synth_pcm
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 mix = [tuple(int(x) for x in m.split("/")) for m in (sys.argv[3] if len(sys.argv) > 3 else "16/32").split(";")]
+taps = tuple(int(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else None      # cascade stage lengths of both channels
 P = api.default_profile()
 raws = [synth_pcm(T, 2, 100 + (i % 16), 44100) for i in range(F)]
 ctx = api.Context(2, T, F)
@@ -21,6 +22,8 @@ for f in range(F):
     profs[f, 24] = min(n0, 32); profs[f, 9] = max(n0 - 32, 0)             # ch0: nA + nM0
     nb = min(n1, 32); rest = n1 - nb
     profs[f, 25] = nb; profs[f, 26] = min(rest, 32); profs[f, 27] = max(rest - 32, 0)   # ch1: nB + nS0 + nS1
+    if taps:
+        profs[f, [28, 29, 30, 37]] = taps; profs[f, [31, 32, 33, 38]] = taps
 ctx.kernel_times(); ctx.class_times()
 t = time.time()
 ctx.predict_final(cfg, profs)
