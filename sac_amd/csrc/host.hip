@@ -584,8 +584,17 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     for (int k = kNumOlsClasses; k < kMark; k++) pool[0].push_back(k);
     for (int k = 0; k < kFastOls; k++) pool[0].push_back(k);
     for (int k = kFastOls; k < kNumOlsClasses; k++) pool[1].push_back(k);
-    size_t used[2] = {0, 0};
-    for (size_t q : lms_order) { const int g = lms_launches[q].group; lms_stream[q] = pool[g][used[g]++ % pool[g].size()]; }
+    // longest first onto the least loaded stream of the group: when a group has more launches than streams, the small launches
+    // queue behind the SMALLEST of the big ones (round-robin put them behind the biggest: a 0.4-s launch of 40 items then started
+    // when the 8-s launch ahead of it had ended, and the generation ended 0.3-0.8 s late: profiles/r04/README.md 7)
+    std::vector<double> load[2];
+    for (int g = 0; g < 2; g++) load[g].assign(pool[g].size(), 0.0);
+    for (size_t q : lms_order) {
+      const int g = lms_launches[q].group;
+      const size_t si = (size_t)(std::min_element(load[g].begin(), load[g].end()) - load[g].begin());
+      lms_stream[q] = pool[g][si];
+      load[g][si] += std::min(work[q], 1e290) + 1.0;
+    }
   }
   auto launch_one = [&](size_t q) -> int {
     const LmsLaunch &ll = lms_launches[q];
