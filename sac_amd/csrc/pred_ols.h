@@ -140,8 +140,8 @@ SA_HD int ols_other_need(const ChanParam &p, int n, int t) {
 // The column loop is a RUN-TIME loop over k whose body is unrolled over register slots: slot q holds column k + q, and the
 // update writes column k + 1 + q's new value into slot q (V[q] = V[q+1] - term), so the pivot column is always slot 0,
 // register indices are compile-time constants, and the code is a few KB whatever the regressor length.
-// Up to 32 taps the covariance row M[l][*] is register-resident too (MREG); beyond, it stays a packed triangle in LDS as in
-// ols_stage_fast.  The forward substitution rides along as before; the backward substitution is the unrolled end-anchored
+// The covariance row M[l][*] is register-resident too (MREG: since round 4 for every class; the packed-triangle-in-LDS path of
+// rounds 1-3 remains selectable at build time, SACAMD_EXP_MREG_MAX).  The forward substitution rides along as before; the backward substitution is the unrolled end-anchored
 // chain over L in LDS (OlsBwdRows).
 template <int N> struct OlsRow { double v[N]; };
 

@@ -423,7 +423,7 @@ def test_canonical_cascade_layout_boundaries_emulated_vs_oracle(emu, orc, taps):
                                         (32, 17, 1), (32, 24, 0), (32, 31, 1), (32, 32, 0), (32, 32, 1)])
 def test_register_resident_ols_kernel_body_vs_oracle(emu, orc, nA, nM0, opt):
     """The one-wave OLS kernel body (right-looking LDL^T on register rows, run-time column loop with rotating register
-    slots; covariance in registers up to 32 taps, in LDS up to 64) at regressor lengths around every capacity class
+    slots; covariance rows in registers) at regressor lengths around every capacity class
     boundary, k = 1 and k = 4: p_lpc bit-identical to the oracle (itself pinned to the genuine reference)."""
     from sac_amd.synth import synth_pcm
     n = 220
