@@ -18,8 +18,8 @@ the ranks by sacamd_assign_frames (cost-based, longest first).
 Every step stages the PCM again (which clears the library's per-batch memo of channel evaluations), so
 each step performs every distinct evaluation of its own search; nothing is carried from step to step.
 
-Wall budget.  One step of the headline workload (768 frames x 20 s per GPU; 384 in rounds 1-2) takes minutes, so K steps
-may not fit the caller's time limit (768 frames: about 4.5 minutes).  --budget-s (default 1200 s, counted from process start) bounds
+Wall budget.  One step of the headline workload (1536 frames x 20 s per GPU; 768 in round 3 and most of round 4, 384 in
+rounds 1-2) takes minutes, so K steps may not fit the caller's time limit (1536 frames: about 7 minutes).  --budget-s (default 1200 s, counted from process start) bounds
 the run: warm-up steps run on a reduced batch (same kernels; there is nothing to warm but code-object
 load), then as many FULL steps as fit are timed, at least one, at most K.  The line reports `steps` =
 steps actually timed and `steps_requested` = K; `ms_per_step` x `steps` is the timed region.
@@ -265,8 +265,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("SAC_BENCH_BUDGET_S", 1200.0)),
                     help="wall budget for the whole run, counted from process start; 0 = none (time exactly --steps)")
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 768)),
-                    help="frames per GPU per step (weak scaling) / in the corpus (strong scaling).  Rounds 1-2 used 384; the batch ends with "
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 1536)),
+                    help="frames per GPU per step (weak scaling) / in the corpus (strong scaling).  Rounds 1-2 used 384, round 3 and the profiles of round 4 768 (6.07 MSamples/s against 6.53 at 1536); the batch ends with "
                          "a latency-bound tail (final pass + coder) that grows 1.4x for twice the frames, so throughput grows with the batch")
     ap.add_argument("--seconds", type=float, default=float(os.environ.get("SAC_BENCH_SECONDS", 20.0)), help="frame length")
     ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
