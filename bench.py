@@ -19,7 +19,7 @@ Every step stages the PCM again (which clears the library's per-batch memo of ch
 each step performs every distinct evaluation of its own search; nothing is carried from step to step.
 
 Wall budget.  One step of the headline workload (1536 frames x 20 s per GPU; 768 in round 3 and most of round 4, 384 in
-rounds 1-2) takes minutes, so K steps may not fit the caller's time limit (1536 frames: about 7 minutes).  --budget-s (default 1200 s, counted from process start) bounds
+rounds 1-2) takes minutes, so K steps may not fit the caller's time limit (1536 frames: about 7 minutes).  --budget-s (default 1500 s, counted from process start; the CPU baselines run first, about 3.5 minutes) bounds
 the run: warm-up steps run on a reduced batch (same kernels; there is nothing to warm but code-object
 load), then as many FULL steps as fit are timed, at least one, at most K.  The line reports `steps` =
 steps actually timed and `steps_requested` = K; `ms_per_step` x `steps` is the timed region.
@@ -263,7 +263,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("SAC_BENCH_BUDGET_S", 1200.0)),
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("SAC_BENCH_BUDGET_S", 1500.0)),
                     help="wall budget for the whole run, counted from process start; 0 = none (time exactly --steps)")
     ap.add_argument("--frames", type=int, default=int(os.environ.get("SAC_BENCH_FRAMES", 1536)),
                     help="frames per GPU per step (weak scaling) / in the corpus (strong scaling).  Rounds 1-2 used 384, round 3 and the profiles of round 4 768 (6.07 MSamples/s against 6.53 at 1536); the batch ends with "
