@@ -196,8 +196,9 @@ def cpu_baseline(frame, framesize, nthreads, mode="high"):
             "bps": 8 * len(r["record"]) / nsamp,
             "sample": f"frame 0 of this run's batch ({secs:g} s stereo 44.1 kHz/16-bit, {nsamp} samples), --{mode} "
                       f"--opt-cfg=dds,{nthreads} --opt-reset; "
-                      + ("genuine reference objects (oracle/_ref), candidates evaluated serially on 1 core"
-                         if kind == "reference" else "oracle restatement, 1 core")}, r["record"]
+                      + ("genuine reference objects (oracle/_ref: the reference's sources compiled in the build container with g++ -O3 -std=c++20 -mavx2 -mfma "
+                         "-fno-math-errno, oracle/Makefile REF_FLAGS -- not -march=native on this box, /root/reference does not travel), candidates evaluated serially on 1 core"
+                         if kind == "reference" else "oracle restatement (g++ -O3 -mavx2 -mfma), 1 core")}, r["record"]
 
 
 _CPU_THREADS_N = None
@@ -208,7 +209,7 @@ def _cpu_encode_one(args):
     frame, framesize, nthreads, mode = args
     chk = Checker("ref" if ref_available() else "orc")
     r = chk.encode_frame(frame, frame_cfg(mode, num_threads=nthreads, reset=1), framesize)
-    return len(r["record"])
+    return bytes(r["record"])
 
 
 def cpu_baseline_all_cores(frames, framesize, nthreads, mode, max_procs=int(os.environ.get("SAC_BENCH_ALLCORES_PROCS", 32))):
@@ -223,10 +224,15 @@ def cpu_baseline_all_cores(frames, framesize, nthreads, mode, max_procs=int(os.e
     jobs = [(frames[i], framesize, nthreads, mode) for i in range(procs)]
     t = time.time()
     with mp.get_context("fork").Pool(procs) as pool:
-        pool.map(_cpu_encode_one, jobs, chunksize=1)
+        recs = pool.map(_cpu_encode_one, jobs, chunksize=1)
     dt = time.time() - t
+    global _CPU_ALL_RECORDS
+    _CPU_ALL_RECORDS = recs          # the reference's records of frames 0..procs-1: compared with the GPU's after the timed region
     return {"value": sum(j[0].size for j in jobs) / dt / 1e6, "unit": "MSamples/s", "cores": procs, "host_cores": cores, "seconds": dt,
             "sample": f"frames 0..{procs - 1} of this run's batch, one process per frame"}
+
+
+_CPU_ALL_RECORDS = None
 
 
 def _verify_one(args):
@@ -444,6 +450,7 @@ def main():
 
     samples_per_step = total_frames * n * 2
     latest = {"line": None}
+    step_seconds = []
 
     def on_term(signum, frame):
         if rank == 0 and latest["line"] is not None:
@@ -470,7 +477,11 @@ def main():
                        "budget_s": args.budget_s},
             "bps": bps, "x_realtime": (total_frames * args.seconds * nsteps) / dt,
             "complete": bool(final),
+            "step_seconds": [round(x, 3) for x in step_seconds],
         }
+        if nsteps < args.steps:
+            out["steps_note"] = (f"--steps {args.steps} asked, {nsteps} timed: one step of this workload takes {dt / nsteps:.0f} s and the run is bounded by --budget-s "
+                                 f"{args.budget_s:g} s from process start (CPU baselines first); --budget-s 0 times exactly --steps")
         out["h2d"] = {"ms": t_h2d * 1e3, "bytes": int(il.nbytes), "in_timed_region": False,
                       "value_incl_h2d": samples_per_step * nsteps / (dt + nsteps * t_h2d) / 1e6,
                       "note": "`value` follows the bench contract (inputs resident in HBM when the timed region starts); value_incl_h2d adds one "
@@ -484,6 +495,14 @@ def main():
             if _CPU_THREADS_N is not None:       # like for like: the reference's own threading for --opt-cfg=dds,N
                 out["speedup_vs_reference_threads"] = value / _CPU_THREADS_N["value"]
             out["cpu_baseline"]["same_record_as_gpu"] = bool(last_recs and last_recs[0] == cb_record)
+            if _CPU_ALL_RECORDS and last_recs:
+                # every record the all-cores baseline computed (the genuine reference, frames 0..P-1) against the GPU's record of the same frame
+                k = min(len(_CPU_ALL_RECORDS), len(last_recs))
+                eq = sum(1 for i in range(k) if bytes(last_recs[i]) == _CPU_ALL_RECORDS[i])
+                ref_bits = 8 * sum(len(_CPU_ALL_RECORDS[i]) for i in range(k)); gpu_bits = 8 * sum(len(last_recs[i]) for i in range(k))
+                out["reference_records_equal"] = f"{eq}/{k}"
+                out["reference_records"] = {"frames": k, "equal": eq, "bps_reference": ref_bits / (k * n * 2), "bps_gpu": gpu_bits / (k * n * 2),
+                                            "delta_bps": (gpu_bits - ref_bits) / (k * n * 2)}
         return out
 
     def add_kernel_report(out, nsteps):
@@ -491,8 +510,12 @@ def main():
         ev = [ctx.eval_stats() for ctx in ctxs]
 
         def kname(kind, cls):
-            if kind == "ols":     # slots 0..7: capacity classes (one-wave kernels up to 64 taps); 11..14: the final pass's panel kernels
-                return f"k_ols<256,{OLS_NMAX[cls - 8]}>" if cls >= 8 else f"k_ols<{64 if cls < 7 else 256},{OLS_NMAX[cls]}>"
+            if kind == "ols":     # slots 0..2: packed kernels (2-4 items per wave), 3..6: one-wave kernels, 7: 65..96 taps; 11..14: the final pass's panel kernels
+                if cls >= 8:
+                    return f"k_ols<256,{OLS_NMAX[cls - 8]}>"
+                if cls < 3 and os.environ.get("SACAMD_OLS_PACK", "1") != "0":     # names as rocprofv3 prints them (kernels_pred.hip: launch_ols)
+                    return ("k_ols_pack<16,16>", "k_ols_pack<24,32>", "k_ols_pack<32,32>")[cls]
+                return f"k_ols<{64 if cls < 7 else 256},{OLS_NMAX[cls]}>"
             return f"k_lms<{cls}>" + (" (canonical order, final pass)" if cls >= 7 else "")
         cands = {}
         for (kind, cls), (ms, launches, isteps, flops) in ct.items():
@@ -561,9 +584,11 @@ def main():
     nsteps = 0
     planned = steps_max
     step = 0
+    t_prev = t0
     while True:
         recs = run_step(0)
         t_done = time.perf_counter()
+        step_seconds.append(t_done - t_prev); t_prev = t_done
         if step == 0:
             t_first = t_done - t0
             left = budget - (time.time() - t_start) - 25.0 - extras_s
@@ -625,6 +650,12 @@ def main():
                     s1 = timed(1)
                     out["single_frame_s"] = s1
                     out["single_frame_MSamples_s"] = n * 2 / s1 / 1e6
+                # the same workload at half the batch (768 frames when the default 1536 is timed): throughput grows with the batch
+                # (the latency-bound tail amortises), so both figures are reported; only when the wall budget still has room
+                kh = nloc // 2
+                if kh >= 64 and time.time() - t_start < budget - (0.62 * dt / nsteps + 30):
+                    sh = timed(kh)
+                    out["half_batch"] = {"frames": kh, "MSamples_s": kh * n * 2 / sh / 1e6, "s_per_step": sh}
             except Exception as e:
                 out["small_batch_error"] = repr(e)
         _flush_c_stdio()                       # (the reference objects print from C++ at load time: keep that ahead of the line)

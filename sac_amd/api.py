@@ -65,7 +65,7 @@ def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, f
 _lib = None
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def load_library():

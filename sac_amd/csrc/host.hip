@@ -258,6 +258,22 @@ PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_
 // main + 8 (OLS capacity classes) + 4 (cascade launches) + 1 (marker).  Work of different contexts on one stream is
 // ordered by that stream, which only ever over-synchronises; every cross-stream dependency is an event owned by the
 // context that recorded it.
+// HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4) and reads that variable when the runtime
+// initialises, i.e. at the process's first HIP call.  The pool below needs 14 streams that really run side by side (plus a main
+// stream per context and the decoder's pair), so the library asks for 24 queues when it is LOADED -- before its own first HIP call,
+// which in a C++ host program (sacenc, framecoder.h) is the first one of the process.  A value the user has set stays; a value too
+// small for the pool makes sacamd_ctx_create fail with a message instead of running 13 kernel classes through 4 queues
+// (SACAMD_ALLOW_FEW_QUEUES=1 overrides).  A host that initialised HIP before loading the library must set the variable itself.
+constexpr int kHwQueuesWanted = 24, kHwQueuesNeeded = 16;
+__attribute__((constructor)) void sacamd_on_load() { (void)setenv("GPU_MAX_HW_QUEUES", "24", /*overwrite=*/0); }
+bool hw_queues_ok(std::string *why) {
+  const char *e = std::getenv("GPU_MAX_HW_QUEUES"), *allow = std::getenv("SACAMD_ALLOW_FEW_QUEUES");
+  const int have = e ? std::atoi(e) : 4;
+  if (have >= kHwQueuesNeeded || (allow && allow[0] == '1')) return true;
+  if (why) *why = "GPU_MAX_HW_QUEUES=" + std::to_string(have) + ": the stream pool needs >= " + std::to_string(kHwQueuesNeeded) + " hardware queues (unset it or set " + std::to_string(kHwQueuesWanted) + "; SACAMD_ALLOW_FEW_QUEUES=1 to run anyway)";
+  return false;
+}
+
 struct DevStreams {
   bool ready = false;
   hipStream_t lo_main = nullptr, lo_cls[sacamd_ctx::kSide] = {};
@@ -448,6 +464,10 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     if (ols_lead[i] == i && !ols_skip[i]) idx_ols[items[i].ols_class].push_back(i);
     idx_lms[items[i].lms_class][group_of_class(items[ols_lead[i]].ols_class)].push_back(i);
   }
+  // the packed kernels (classes 0..2: several work-items per wave) run ONE solve-interval counter per wave (pred_ols_pack.h), which is
+  // the reference's per-instance km >= kmax (pred/ols.cpp:46-55) only when every item of the launch has the same k
+  for (int k = 0; k < 3; k++)
+    for (int i : idx_ols[k]) if (items[i].p.k != items[idx_ols[k][0]].p.k) return fail(c, SACAMD_ERR_ARG, "packed OLS launch with mixed solve intervals k");
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
   std::vector<int> flat;
@@ -638,7 +658,7 @@ void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start
 }  // namespace
 
 // ================================================================== context
-API int sacamd_abi_version(void) { return 3; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*)
+API int sacamd_abi_version(void) { return 4; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*); 4: the gather's first all-gather carries 4 words per rank (ranks of different builds must not meet), sacamd_debug_libm
 
 API void sacamd_default_cfg(sacamd_cfg *cfg) {
   std::memset(cfg, 0, sizeof(*cfg));
@@ -657,6 +677,7 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   if (!out) return SACAMD_ERR_ARG;
   *out = nullptr;
   if (nch < 1 || nch > 2 || max_framesize < 1 || max_frames < 1) return SACAMD_ERR_ARG;
+  { std::string why; if (!hw_queues_ok(&why)) { std::fprintf(stderr, "sac_amd: %s\n", why.c_str()); return SACAMD_ERR_STATE; } }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SACAMD_ERR_NOGPU;
   hipDeviceProp_t prop;
@@ -770,7 +791,7 @@ API int sacamd_frames_attach_s16_device(sacamd_ctx *c, int nframes, int framesiz
 }
 
 // ================================================================== (2) analyse
-API int sacamd_analyse(sacamd_ctx *c, const sacamd_cfg *cfg) {
+static int analyse_body(sacamd_ctx *c, const sacamd_cfg *cfg) {
   if (!c || !cfg) return SACAMD_ERR_ARG;
   if (c->nframes < 1 || !c->raw_kind) return fail(c, SACAMD_ERR_STATE, "no frames staged");
   HIPCHK(c, hipSetDevice(c->device));
@@ -858,7 +879,7 @@ int run_costs(sacamd_ctx *c, int kind, const std::vector<long long> &off, const 
 }  // namespace
 
 // ================================================================== (3) evaluate
-API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const int *cand_frame, const float *coefs, double *costs) {
+static int evaluate_body(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const int *cand_frame, const float *coefs, double *costs) {
   if (!c || !cfg || ncand < 0 || (ncand && (!cand_frame || !coefs || !costs))) return SACAMD_ERR_ARG;
   if (!c->analysed) return fail(c, SACAMD_ERR_STATE, "analyse first");
   if (!ncand) return 0;
@@ -940,7 +961,7 @@ API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const i
 }
 
 // ================================================================== (4) final pass
-API int sacamd_predict_final(sacamd_ctx *c, const sacamd_cfg *cfg, const float *coefs) {
+static int predict_final_body(sacamd_ctx *c, const sacamd_cfg *cfg, const float *coefs) {
   if (!c || !cfg || !coefs) return SACAMD_ERR_ARG;
   if (!c->analysed) return fail(c, SACAMD_ERR_STATE, "analyse first");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1098,7 +1119,7 @@ API int sacamd_subframes_from_states(const int *block_state, const int *block_le
   return (int)sf.size() > cap && out ? SACAMD_ERR_ARG : 0;
 }
 
-API int sacamd_plan_subframes(sacamd_ctx *c, const int32_t *pcm, long long ch_stride, int nch, int samples_read,
+static int plan_subframes_body(sacamd_ctx *c, const int32_t *pcm, long long ch_stride, int nch, int samples_read,
                               int blocksamples, int min_frame_length, sacamd_subframe *out, int cap, int *count) {
   if (!c || !pcm || !count || nch < 1 || samples_read < 0 || blocksamples < 1) return SACAMD_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
@@ -1226,4 +1247,46 @@ API int sacamd_kernel_times(sacamd_ctx *c, double *out16, int reset) {
 
 #include "host_encode.inc"
 #include "host_decode.inc"
+
+// ================================================================== C ABI: no exception leaves the library
+// The entry points that build batch-sized bookkeeping on the host (std::vector / std::map / std::string) run behind this guard: a
+// std::bad_alloc becomes SACAMD_ERR_HIP with a message instead of crossing the extern "C" boundary.
+namespace {
+template <class F>
+int guarded(sacamd_ctx *c, const char *what, F &&f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return fail(c, SACAMD_ERR_HIP, std::string(what) + ": out of host memory");
+  } catch (const std::exception &e) {
+    return fail(c, SACAMD_ERR_HIP, std::string(what) + ": " + e.what());
+  }
+}
+}  // namespace
+API int sacamd_analyse(sacamd_ctx *c, const sacamd_cfg *cfg) {
+  return guarded(c, "sacamd_analyse", [&] { return analyse_body(c, cfg); });
+}
+API int sacamd_evaluate(sacamd_ctx *c, const sacamd_cfg *cfg, int ncand, const int *cand_frame, const float *coefs, double *costs) {
+  return guarded(c, "sacamd_evaluate", [&] { return evaluate_body(c, cfg, ncand, cand_frame, coefs, costs); });
+}
+API int sacamd_predict_final(sacamd_ctx *c, const sacamd_cfg *cfg, const float *coefs) {
+  return guarded(c, "sacamd_predict_final", [&] { return predict_final_body(c, cfg, coefs); });
+}
+API int sacamd_plan_subframes(sacamd_ctx *c, const int32_t *pcm, long long ch_stride, int nch, int samples_read, int blocksamples, int min_frame_length, sacamd_subframe *out, int cap, int *count) {
+  return guarded(c, "sacamd_plan_subframes", [&] { return plan_subframes_body(c, pcm, ch_stride, nch, samples_read, blocksamples, min_frame_length, out, cap, count); });
+}
+API int sacamd_encode(sacamd_ctx *c, const sacamd_cfg *cfg) {
+  return guarded(c, "sacamd_encode", [&] { return encode_body(c, cfg); });
+}
+API int sacamd_search_frames(sacamd_ctx *c, const sacamd_cfg *cfg, float *profiles_io) {
+  return guarded(c, "sacamd_search_frames", [&] { return search_frames_body(c, cfg, profiles_io); });
+}
+API int sacamd_encode_frames(sacamd_ctx *c, const sacamd_cfg *cfg, float *profiles_io, uint8_t *out, long long cap, long long *rec_off) {
+  return guarded(c, "sacamd_encode_frames", [&] { return encode_frames_body(c, cfg, profiles_io, out, cap, rec_off); });
+}
+API int sacamd_decode_frames(sacamd_ctx *c, int nframes, int framesize, const uint8_t *recs, const long long *rec_off,
+                             int32_t *pcm_out, long long frame_stride, long long ch_stride, int *numsamples_out, float *profiles_out) {
+  return guarded(c, "sacamd_decode_frames", [&] { return decode_frames_body(c, nframes, framesize, recs, rec_off, pcm_out, frame_stride, ch_stride, numsamples_out, profiles_out); });
+}
+
 #include "host_gather.inc"

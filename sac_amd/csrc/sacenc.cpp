@@ -57,6 +57,7 @@ int main(int argc, char **argv) {
     bool decode_mode = false;      // --decode
     int world = 1, rank = 0, device = -1;   // --world / --rank / --device: one process per GPU
     std::string comm_id_file;
+    bool job_tag_given = false;
     unsigned long long job_tag = 0; // --job-tag=N: ties the rendezvous file to this job (stale files of other runs are ignored)
     bool force_gather = false;     // --force-gather: take the communicator / gather path with one rank too (one-GPU test)
     bool header_only = false;      // --header-only: write header + MD5 of each input and stop (no device needed; tests)
@@ -95,7 +96,7 @@ int main(int argc, char **argv) {
       else if (a.rfind("--rank=", 0) == 0) rank = std::atoi(a.c_str() + 7);
       else if (a.rfind("--device=", 0) == 0) device = std::atoi(a.c_str() + 9);
       else if (a.rfind("--comm-id=", 0) == 0) comm_id_file = a.substr(10);
-      else if (a.rfind("--job-tag=", 0) == 0) job_tag = std::strtoull(a.c_str() + 10, nullptr, 10);
+      else if (a.rfind("--job-tag=", 0) == 0) { job_tag = std::strtoull(a.c_str() + 10, nullptr, 10); job_tag_given = true; }
       else if (a == "--force-gather") force_gather = true;
       else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
       else pos.push_back(a);
@@ -191,6 +192,16 @@ int main(int argc, char **argv) {
     const bool use_comm = world > 1 || force_gather;
     if (world < 1 || rank < 0 || rank >= world || (use_comm && comm_id_file.empty())) { std::cerr << "sacenc: --world=W --rank=R (0 <= R < W) --comm-id=FILE\n"; return 2; }
     if (device < 0) device = rank;                     // one process per GPU: rank r drives GPU r unless told otherwise
+    if (world > 1 && !job_tag_given) {
+      // no --job-tag: take what the launcher provides (the same value on every rank of ONE job); none -> refuse, because with a
+      // shared default tag a rank could pick up the id file a crashed run of the same world size left behind and hang in
+      // ncclCommInitRank (round-4 advice)
+      for (const char *var : {"SACENC_JOB_TAG", "SLURM_JOB_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"}) {
+        const char *e = std::getenv(var);
+        if (e && *e) { unsigned long long h = 1469598103934665603ull; for (const char *q = e; *q; q++) h = (h ^ (unsigned char)*q) * 1099511628211ull; job_tag = h; job_tag_given = true; break; }
+      }
+      if (!job_tag_given) { std::cerr << "sacenc: --world > 1 needs --job-tag=N (or SACENC_JOB_TAG / SLURM_JOB_ID / TORCHELASTIC_RUN_ID / MASTER_PORT in the environment), the same on every rank of this job\n"; return 2; }
+    }
     if (use_comm && !cfg.reset) throw std::runtime_error("frames are sharded across ranks: --opt-reset semantics only");
     sacamd_ctx *ctx = nullptr;
     if (sacamd_ctx_create(device, nch, maxfs, max_frames, &ctx) != 0) throw std::runtime_error("no usable gfx950 device (sacamd_ctx_create failed)");

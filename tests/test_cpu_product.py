@@ -38,7 +38,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     import sac_amd.api as api
     assert sorted(api.ABI_SYMBOLS) == declared
-    assert lib.sacamd_abi_version() == api.ABI_VERSION == 3
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 4
     # without a GPU the context constructor must fail loudly (no CPU fallback)
     import torch
     if not torch.cuda.is_available():
@@ -254,7 +254,7 @@ ids = np.array([rank], np.int32); blob = np.frombuffer(b"q" * 10, np.uint8).copy
 out = np.zeros(64, np.uint8); out_off = np.zeros(3, np.int64)
 rc = lib.sacamd_gather_records_via(ctypes.byref(tr), -1 if rank == 1 else 1, api._vp(ids), api._vp(blob), api._vp(off), 2,
                                    api._vp(out) if rank == 0 else None, ctypes.c_longlong(64 if rank == 0 else 0), api._vp(out_off) if rank == 0 else None)
-assert rc != 0, rc
+assert rc == -6, rc        # SACAMD_ERR_COMM on EVERY rank, the reporting one included (include/sac_amd.h)
 # bad arguments on rank 0 only (no out_off): both ranks return an error together
 rc = lib.sacamd_gather_records_via(ctypes.byref(tr), 1, api._vp(ids), api._vp(blob), api._vp(off), 2, api._vp(out) if rank == 0 else None,
                                    ctypes.c_longlong(64 if rank == 0 else 0), None)

@@ -28,7 +28,7 @@ def gpu_cfg(api, cfg):
 
 def test_library_is_the_hip_one(api):
     lib = api.load_library()
-    assert lib.sacamd_abi_version() == api.ABI_VERSION == 3
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 4
     ctx = api.Context(2, 1000, 1)   # fails loudly without a gfx950 device
     ctx.close()
     assert np.array_equal(api.default_profile(), np.load(__import__("os").path.join(
@@ -822,12 +822,10 @@ def test_baseline_configs_3_and_4_full_size_vs_reference(api, name):
     """BASELINE configs[3] (--best: CostBitplane objective over a 441 000-sample window) and configs[4] (--veryhigh, 176 400-sample
     window; 8-bit mono and 16-bit stereo) on ONE full 882 000-sample frame each, evaluation count cut to 17 / 25 (dds,8): the
     record (SHA-256, length) and the chosen profile equal the genuine reference's (ref_golden_r5.npz, made here from oracle/_ref
-    by make_golden.py --r5).  A single 20-s frame is a latency-bound chain (2-3 minutes per case), so the default run takes
-    --best and the 8-bit --veryhigh case; SACAMD_SLOW_TESTS=1 adds the 16-bit --veryhigh case and the GPU decoder round trip of
-    every case (all three with the round trip: profiles/r04/gputests_full_03.log, 66 passed)."""
+    by make_golden.py --r5).  A single 20-s frame is a latency-bound chain (2-3 minutes per case), all three
+    cases run by default since round 5; SACAMD_SLOW_TESTS=1 adds the GPU decoder round trip of every case (all three with the
+    round trip: profiles/r04/gputests_full_03.log, 66 passed)."""
     import hashlib, os
-    if name == "vh_s16_e25" and not _slow_cases():
-        pytest.skip("third full-size case: SACAMD_SLOW_TESTS=1 (passed in profiles/r04/gputests_full_03.log)")
     g5 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_golden_r5.npz"))
     raw, cfg = config34_cases()[name]
     assert hashlib.sha256(raw.astype(np.int16).tobytes()).digest() == g5[f"cfg/{name}/raw_sha256"].tobytes()     # (the PCM is regenerated from its seed)
