@@ -6,6 +6,7 @@
 #include "pred_lms.h"
 #include "pred_ols.h"
 #include "pred_ols_pack.h"
+#include "pred_ols_grid.h"
 #include "pred_tables.h"
 
 #include <atomic>
@@ -139,6 +140,28 @@ static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_id
   hipLaunchKernelGGL((k_ols<NL, NMAX>), dim3(count), dim3(NL), bytes, s, d_items, d_idx, v, d_p);
 }
 
+// 33..64 taps on one wave, matrix 2D-cyclic over the lanes (pred_ols_grid.h): NB = blocks of 8 rows / columns.  158 / 188 / 219 / 256
+// registers for NB = 5 .. 8 (the backward solve keeps its operands sixteen to a register, DPP row broadcast): three waves per SIMD for
+// the 40-tap instance, two for the others; search and final pass run the same build.
+template <int NB> constexpr int grid_waves() { return NB <= 5 ? 3 : 2; }
+template <int NB>
+__global__ __launch_bounds__(64, (grid_waves<NB>())) void k_ols_grid(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (idx[blockIdx.x] < 0) return;                 // padding entry of the XCD-interleaved launch list
+  const WorkItem &it = items[idx[blockIdx.x]];
+  const ChanParam p = it.p;
+  const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
+  const int *other = v.pcm + it.frame * v.frame_stride + it.ch_other * v.ch_stride + it.start;
+  ExecDev<64> ex;
+  double *out = (it.pin_kept ? v.keep : pbuf) + it.off_pin;
+  ols_stage_grid<ExecDev<64>, NB>(ex, p, self, other, it.n, out, smem, v.prof);
+}
+template <int NB>
+static void launch_ols_grid_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
+  const size_t bytes = OlsLdsGrid::bytes(8 * NB);       // <= 24 KB: below the default dynamic-LDS limit
+  hipLaunchKernelGGL((k_ols_grid<NB>), dim3(count), dim3(64), bytes, s, d_items, d_idx, v, d_p);
+}
+
 constexpr int kOlsPanelThreads = 256;   // panel width 4 (8 waves measured slower: one workgroup per CU, and a barrier-parked wave sharing the SIMD of wave 0 doubles the time of its serial solve)
 // latency_bound: the final pass (k = 1: one factorisation per sample, one work-item per frame x channel).  Its 33..64-tap items
 // take the four-wave panel kernel, whose per-sample latency is lower (28 vs 34 us at 48 taps); the search (thousands of items
@@ -150,6 +173,17 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
   const bool panel = force >= 0 ? (force == 1 && latency_bound) : latency_bound;
   // regressors up to 32 taps: several work-items per wave (pred_ols_pack.h); SACAMD_OLS_PACK=0 selects the one-item-per-wave kernel (A/B)
   static const bool pack = [] { const char *e = std::getenv("SACAMD_OLS_PACK"); return !(e && e[0] == '0'); }();
+  // 33..64 taps: the 2D-cyclic one-wave kernel (round 5) for search AND final pass; SACAMD_OLS_GRID=0 selects the round-4 kernels (A/B)
+  static const bool grid = [] { const char *e = std::getenv("SACAMD_OLS_GRID"); return !(e && e[0] == '0'); }();
+  if (grid && ols_class >= 3 && ols_class <= 6) {
+    switch (ols_class) {
+      case 3: launch_ols_grid_c<5>(s, d_items, d_idx, count, v, d_p); break;
+      case 4: launch_ols_grid_c<6>(s, d_items, d_idx, count, v, d_p); break;
+      case 5: launch_ols_grid_c<7>(s, d_items, d_idx, count, v, d_p); break;
+      default: launch_ols_grid_c<8>(s, d_items, d_idx, count, v, d_p); break;
+    }
+    return;
+  }
   switch (ols_class) {
     case 0: if (pack) launch_ols_pack_c<16, 16>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 16>(s, d_items, d_idx, count, v, d_p); break;
     case 1: if (pack) launch_ols_pack_c<24, 32>(s, d_items, d_idx, count, v, d_p); else launch_ols_c<64, 24>(s, d_items, d_idx, count, v, d_p); break;

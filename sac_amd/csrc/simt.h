@@ -120,6 +120,10 @@ struct ExecEmu {
   template <int GL, class R> void grp_bcast_col(Reg<double> &dst, const R &src, int col, int k) { for (int l = 0; l < NL; l++) dst[l] = src[(l / GL) * GL + k].v[col]; }
   // every lane takes the value of lane-1 (lane 0 keeps its own): DPP wave_shr:1 on the device
   void shift_up1(Reg<double> &r) { for (int l = NL - 1; l > 0; l--) r[l] = r[l - 1]; }
+  // uniform code: fma(value lane Q of the calling lane's row of 16 lanes holds in r, w, s) resp. that value itself.  The device runs
+  // uniform code on all lanes, every row of 16 holding the same 16 values (the emulator's single instance stands for row 0).
+  template <int Q> double row_bcast_fma(const Reg<double> &r, double w, double s) { return fma(r[Q], w, s); }
+  template <int Q> double row_bcast(const Reg<double> &r) { return r[Q]; }
   // trip count of a loop whose length differs between the waves of a workgroup: lanes < split run a iterations, the others
   // b (device: the calling wave's own count, wave-uniform; the emulator runs the lanes of all waves in one loop)
   int wave_hops(int, int a, int b) { return a > b ? a : b; }
@@ -264,6 +268,18 @@ struct ExecDev {
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
     r.v = __hiloint2double(hi, lo);
+  }
+  // DP-ALU DPP (gfx90a+): src0 of the instruction = lane Q of the reading lane's row of 16 lanes; ONE instruction per term of a
+  // serial fp64 chain whose operands arrive sixteen to a register (pred_ols_grid.h: backward substitution).  All lanes must be
+  // active (a disabled source lane is not read).
+  template <int Q> static SA_D double row_bcast_fma(const Reg<double> &r, double w, double s) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(r.v), "v"(w), "n"(Q));
+    return s;
+  }
+  template <int Q> static SA_D double row_bcast(const Reg<double> &r) {
+    double z;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(z) : "v"(r.v), "n"(Q));
+    return z;
   }
   static SA_D int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
   SA_D int wave_hops(int split, int a, int b) { return __builtin_amdgcn_readfirstlane(tid() < split ? a : b); }
