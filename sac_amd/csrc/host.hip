@@ -453,12 +453,17 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16));
   HIPCHK(c, c->d_idx.ensure((size_t)count * 2 + 16));
   HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
-  // class lists, heaviest first.  Cascade items are additionally split by how long their OLS class
-  // runs (group 0: one-wave classes <= 32 taps, group 1: the panel classes): a cascade launch only
-  // waits for the OLS classes of its own group, so cascade work starts under the OLS tail.
-  constexpr int kFastOls = 3;                       // search: OLS classes [0, kFastOls) form group 0
-  constexpr int ngroups = 2;
-  auto group_of_class = [&](int ols_class) { return ols_class >= kFastOls ? 1 : 0; };
+  // class lists, heaviest first.  Cascade items are additionally split by the OLS class that produces their input: a cascade launch
+  // only waits for the OLS classes of its own group, so cascade work starts under the tail of the slower OLS classes.  Search: two
+  // groups (OLS classes [0, kFastOls) and the rest: more groups mean more, smaller launches, measured as a loss in round 4).  The same
+  // in the final pass; one group per OLS class there (SACAMD_FINAL_GROUPS=1) lost as well: 202.2 vs 194.5 s per step at 768 frames,
+  // twenty-odd launches whose whole-CU workgroups wait for drained CUs (profiles/r05/final_pass_timeline_768_grid_groups.txt).
+  static const int fast_env = [] { const char *e = std::getenv("SACAMD_FAST_OLS"); return e ? std::atoi(e) : -1; }();
+  static const bool final_groups = [] { const char *e = std::getenv("SACAMD_FINAL_GROUPS"); return e && e[0] == '1'; }();   // measured as a loss (202 vs 194.5 s at 768 frames, profiles/r05): off
+  const int kFastOls = fast_env >= 1 && fast_env <= kNumOlsClasses - 1 ? fast_env : 3;      // search: OLS classes [0, kFastOls) form group 0
+  const bool per_class = want_pred && final_groups;
+  const int ngroups = per_class ? kNumOlsClasses : 2;
+  auto group_of_class = [&](int ols_class) { return per_class ? ols_class : (ols_class >= kFastOls ? 1 : 0); };
   std::vector<int> idx_ols[kNumOlsClasses], idx_lms[kNumLmsClasses][kNumOlsClasses];
   for (int i = 0; i < count; i++) {
     if (ols_lead[i] == i && !ols_skip[i]) idx_ols[items[i].ols_class].push_back(i);
@@ -530,50 +535,22 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   constexpr int kMark = sacamd_ctx::kSide - 1;
   HIPCHK(c, hipStreamWaitEvent(side[kMark], c->ev_fork, 0));
-  // Which kernel the 33..64-tap classes (3..6) take.  The panel kernel (four waves per item, two workgroups per CU by its
-  // registers) is ~1.2-1.5x faster per sample for ONE item but needs four wave slots; what a launch costs is its slowest item,
-  // as long as every item is resident at once.  So the panel kernel goes to the longest classes first while the launch still
-  // fits the chip in one residency round (2 workgroups x CUs), the rest takes the one-wave kernel.  Round 3 ran the whole
-  // final pass on panel kernels: at 768 frames 724 panel workgroups for 512 slots -- two rounds of a 28-s kernel (56 s) -- and
-  // the search on one-wave kernels only, where a 56- / 64-tap class of a few hundred items was the last OLS kernel of its
-  // generation to end (profiles/r03/README.md, profiles/r04/README.md).  SACAMD_OLS_PANEL_SLOTS overrides the slot budget (A/B).
-  bool use_panel[kNumOlsClasses] = {};
-  {
-    static const int slots_env = [] { const char *e = std::getenv("SACAMD_OLS_PANEL_SLOTS"); return e ? std::atoi(e) : -1; }();
-    // (13/20 of the slots: with every slot taken -- 508 panel workgroups for 512 -- a few of them wait for a whole kernel generation of
-    //  the others, and the one-wave classes starve: 233.7 s per step; at 330 of 512: 222.2 s, profiles/r04/README.md)
-    int budget = slots_env >= 0 ? slots_env : (2 * c->num_cus * 13) / 20;
-    if (!want_pred) budget /= 4;                   // search: the chip is shared with the other classes and the cascade launches
-    for (int k = 6; k >= 3; k--) {
-      const int m = (int)idx_ols[k].size();
-      if (m > 0 && m <= budget) { use_panel[k] = true; budget -= m; }
-    }
-    use_panel[7] = true;                           // 65..96 taps: only the panel kernel exists
-  }
-  // Final pass: the panel launches go first and get a head start.  A panel workgroup needs a wave slot on all four SIMDs of a CU;
-  // once one-wave waves of the other classes sit on the SIMDs, panel workgroups wait for whole CUs to drain (the 56-tap class took
-  // 72.7 s instead of 43 s when the faster one-wave kernels of round 4 were submitted at the same moment).  So the one-wave
-  // classes are submitted a few milliseconds after the panel kernels have started, when every panel workgroup is resident.
-  static const int stagger_us = [] { const char *e = std::getenv("SACAMD_PANEL_STAGGER_US"); return e ? std::atoi(e) : 5000; }();
-  bool panel_launched = false, staggered = false;
+  // (Round 5 also tried the final pass on a partitioned chip -- hipExtStreamCreateWithCUMask: the long OLS classes on 12-20 CUs per XCD,
+  //  the short classes and their cascades on the rest, so that the whole-CU cascade layouts find drained CUs early.  The masks work
+  //  (tools/probe_cumask.hip), but with masked queues in use EVERY kernel of the process ran ~25 % slower (coder 24.2 instead of
+  //  18.9 s, 64-tap OLS 43.4 instead of 38.5 s): 214-229 s per step against 194.5 s unpartitioned at 768 frames, profiles/r05.)
+  // Every class up to 64 taps is a one-wave kernel since round 5 (packed <= 32 taps, 2D-cyclic 33..64: kernels_pred.hip launch_ols);
+  // the four-wave panel kernels of rounds 1-4, their slot budget and the host-side head start they needed are gone.  Heaviest class
+  // first: its items are the long pole.
   for (int q = 0; q < kNumOlsClasses; q++) {
-    const int k = kNumOlsClasses - 1 - q;            // heaviest class first: its items are the long pole
+    const int k = kNumOlsClasses - 1 - q;
     if (idx_ols[k].empty()) continue;
-    if (want_pred && stagger_us > 0 && panel_launched && !staggered && !use_panel[k]) {
-      HIPCHK(c, hipEventSynchronize(c->ev_fork));      // the panel kernels' only dependency
-      usleep(stagger_us);
-      staggered = true;
-    }
-    if (use_panel[k]) panel_launched = true;
     hipStream_t st = side[k];
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0));
     {
       double isteps = 0, fl = 0; for (int i : idx_ols[k]) { isteps += items[i].n; fl += ols_flops(items[i]); }
-      // statistics slot: 33..64-tap items run either on the one-wave kernel (throughput) or on the four-wave panel kernel (lower
-      // latency per sample, four times the wave slots): two kernel instances of one capacity class -> slots 8 + k for the latter
-      const bool panel_k = use_panel[k];
-      Trace tr(c, st, "ols", (panel_k && k >= 3 && k <= 6) ? 8 + k : k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
-      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, panel_k);
+      Trace tr(c, st, "ols", k, (int)idx_ols[k].size(), items[0].n, isteps, fl);
+      launch_ols(st, c->d_items.p, c->d_idx.p + base_ols[k], cnt_ols[k], k, pv, c->d_p.p, want_pred);
     }
     HIPCHK(c, hipEventRecord(c->ev_ols[k], st));
     HIPCHK(c, hipStreamWaitEvent(side[kMark], c->ev_ols[k], 0));
@@ -600,20 +577,25 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     }
     std::stable_sort(lms_order.begin(), lms_order.end(), [&](size_t a, size_t b) {
       return lms_launches[a].group != lms_launches[b].group ? lms_launches[a].group < lms_launches[b].group : work[a] > work[b]; });
-    std::vector<int> pool[2];
-    for (int k = kNumOlsClasses; k < kMark; k++) pool[0].push_back(k);
-    for (int k = 0; k < kFastOls; k++) pool[0].push_back(k);
-    for (int k = kFastOls; k < kNumOlsClasses; k++) pool[1].push_back(k);
+    // streams a group's launches may use: the four cascade streams are shared by all groups; search: group 0 also takes the streams
+    // of the fast OLS classes (those kernels are exactly what it waits for), group 1 those of the slow classes; final pass: group k
+    // takes the stream of OLS class k
+    std::vector<std::vector<int>> pool(ngroups);
+    for (int g = 0; g < ngroups; g++) {
+      if (per_class) { pool[g].push_back(g); for (int k = kNumOlsClasses; k < kMark; k++) pool[g].push_back(k); }
+      else if (g == 0) { for (int k = kNumOlsClasses; k < kMark; k++) pool[0].push_back(k); for (int k = 0; k < kFastOls; k++) pool[0].push_back(k); }
+      else for (int k = kFastOls; k < kNumOlsClasses; k++) pool[1].push_back(k);
+    }
     // longest first onto the least loaded stream of the group: when a group has more launches than streams, the small launches
     // queue behind the SMALLEST of the big ones (round-robin put them behind the biggest: a 0.4-s launch of 40 items then started
     // when the 8-s launch ahead of it had ended, and the generation ended 0.3-0.8 s late: profiles/r04/README.md 7)
-    std::vector<double> load[2];
-    for (int g = 0; g < 2; g++) load[g].assign(pool[g].size(), 0.0);
+    std::vector<double> load(sacamd_ctx::kSide, 0.0);
     for (size_t q : lms_order) {
       const int g = lms_launches[q].group;
-      const size_t si = (size_t)(std::min_element(load[g].begin(), load[g].end()) - load[g].begin());
-      lms_stream[q] = pool[g][si];
-      load[g][si] += std::min(work[q], 1e290) + 1.0;
+      int best = pool[g][0];
+      for (int si : pool[g]) if (load[si] < load[best]) best = si;
+      lms_stream[q] = best;
+      load[best] += std::min(work[q], 1e290) + 1.0;
     }
   }
   auto launch_one = [&](size_t q) -> int {
