@@ -253,6 +253,28 @@ int sacamd_progress(const sacamd_ctx *ctx, int *phase, int *generation);
  * [12] stage gains / experts / P x [13] RLS scalars + blend [14] P update [15] closing barrier */
 int sacamd_debug_ols_profile(sacamd_ctx *ctx, int on, unsigned long long *out16);
 
+/* ---- Predictor surface ------------------------------------------------------------------
+ * Replaces: Predictor (libsac/pred.h:9-42, pred.cpp:4-46) for the ENCODER: its tparam, flattened, and the streams a
+ * Predictor(r0, r1, tparam) yields when FrameCoder::PredictFrame (libsac.cpp:113-141) drives it over a frame -- pd[slot][t] = what
+ * predict(slot) returns at sample t, p_lpc[slot][t], p_lms[slot][t] (nullable).  src0 / src1: the mean-removed samples of the
+ * slot-0 / slot-1 channel (what the caller passes to fillbuf_ch0 / fillbuf_ch1; ch_ref has already been applied by the caller,
+ * as in libsac.cpp:119-125); range4 = {r0.lo, r0.hi, r1.lo, r1.hi}.  The cascade sums in slmath::dot order whatever k, so pd and
+ * p_lpc are the reference's to the last bit.  The context must have been created for nch channels and >= numsamples samples; the
+ * call replaces the context's staged batch.  sac_amd/csrc/predictor.h wraps this in the reference's class (ABI version 5). */
+typedef struct sacamd_pred_tparam {
+  int nA, nB, nM0, nS0, nS1, k;
+  int vn0[4], vn1[4];
+  double vmu0[4], vmu1[4], vmudecay0[4], vmudecay1[4], vpowdecay0[4], vpowdecay1[4];
+  double lambda0, lambda1, ols_nu0, ols_nu1, mu_mix0, mu_mix1, mu_mix_beta0, mu_mix_beta1;
+  double beta_sum0, beta_pow0, beta_add0, beta_sum1, beta_pow1, beta_add1;
+  int ch_ref;
+  double bias_mu0, bias_mu1;
+  int bias_scale0, bias_scale1, lm_n;
+  double lm_alpha, proj_alpha0, proj_alpha1;
+} sacamd_pred_tparam;
+int sacamd_predictor_streams(sacamd_ctx *ctx, int nch, const int32_t *src0, const int32_t *src1, int numsamples, const int32_t *range4,
+                             const sacamd_pred_tparam *tp, double *pd, double *p_lpc, double *p_lms);
+
 int sacamd_abi_version(void);
 
 #ifdef __cplusplus

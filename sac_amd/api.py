@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
     "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
     "sacamd_decode_frames", "sacamd_comm_unique_id", "sacamd_comm_create", "sacamd_comm_destroy", "sacamd_comm_last_error",
-    "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_debug_libm",
+    "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_debug_libm", "sacamd_predictor_streams",
 ]
 
 
@@ -65,7 +65,44 @@ def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, f
 _lib = None
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+
+
+class PredTParam(ctypes.Structure):
+    """sacamd_pred_tparam (include/sac_amd.h) == Predictor::tparam (libsac/pred.h:11-27), flattened"""
+    _fields_ = ([(k, c_int) for k in ("nA", "nB", "nM0", "nS0", "nS1", "k")] + [("vn0", c_int * 4), ("vn1", c_int * 4)] +
+                [(k, c_double * 4) for k in ("vmu0", "vmu1", "vmudecay0", "vmudecay1", "vpowdecay0", "vpowdecay1")] +
+                [(k, c_double) for k in ("lambda0", "lambda1", "ols_nu0", "ols_nu1", "mu_mix0", "mu_mix1", "mu_mix_beta0", "mu_mix_beta1",
+                                         "beta_sum0", "beta_pow0", "beta_add0", "beta_sum1", "beta_pow1", "beta_add1")] +
+                [("ch_ref", c_int), ("bias_mu0", c_double), ("bias_mu1", c_double), ("bias_scale0", c_int), ("bias_scale1", c_int), ("lm_n", c_int),
+                 ("lm_alpha", c_double), ("proj_alpha0", c_double), ("proj_alpha1", c_double)])
+
+
+def tparam_from_profile(coefs, optimize: bool, optk: int = 4) -> PredTParam:
+    """FrameCoder::SetParam (libsac.cpp:37-92): 58 float32 coefficients -> Predictor::tparam"""
+    g = np.asarray(coefs, np.float32)
+    G = lambda i: float(g[i])                       # profile.Get(i): the float32 value, widened
+    R = lambda i: int(np.sign(g[i]) * np.floor(abs(float(g[i])) + 0.5))      # std::round: half away from zero
+    t = PredTParam()
+    t.k = optk if optimize else 1
+    t.vn0[:] = [R(28), R(29), R(30), R(37)]; t.vn1[:] = [R(31), R(32), R(33), R(38)]
+    t.vmu0[:] = [G(2) / float(t.vn0[0]), G(3) / float(t.vn0[1]), G(4) / float(t.vn0[2]), G(5) / float(t.vn0[3])]
+    t.vmu1[:] = [G(14) / float(t.vn1[0]), G(15) / float(t.vn1[1]), G(16) / float(t.vn1[2]), G(17) / float(t.vn1[3])]
+    t.vmudecay0[:] = [G(6), G(39), G(46), G(47)]; t.vpowdecay0[:] = [G(7), G(8), G(50), G(51)]
+    t.vmudecay1[:] = [G(18), G(40), G(48), G(49)]; t.vpowdecay1[:] = [G(19), G(20), G(21), G(52)]
+    t.lambda0, t.ols_nu0, t.lambda1, t.ols_nu1 = G(0), G(1), G(12), G(13)
+    t.mu_mix0, t.mu_mix_beta0, t.mu_mix1, t.mu_mix_beta1 = G(10), G(11), G(22), G(23)
+    t.nA, t.nB, t.nS0, t.nS1, t.nM0 = R(24), R(25), R(26), R(27), R(9)
+    t.beta_sum0, t.beta_pow0, t.beta_add0 = G(34), G(35), G(36)
+    t.beta_sum1, t.beta_pow1, t.beta_add1 = G(53), G(54), G(55)
+    t.proj_alpha0, t.proj_alpha1 = G(56), G(57)
+    t.lm_n, t.lm_alpha = R(41), G(42)
+    t.bias_mu0, t.bias_mu1 = G(43), G(44)
+    t.bias_scale0 = t.bias_scale1 = R(45)
+    t.ch_ref = 0
+    if t.nS1 < 0:
+        t.nS1 = -t.nS1; t.ch_ref = 1
+    return t
 
 
 def load_library():
@@ -408,6 +445,17 @@ class Context:
         self._chk(self.lib.sacamd_debug_predict(self.h, frame, _vp(g), start, n, int(optimize), optk, _vp(plpc), _vp(psum),
                                                 _vp(err), _vp(pred)))
         return plpc, psum, err, pred
+
+    def predictor_streams(self, src, range4, tp: "PredTParam"):
+        """Predictor surface (libsac/pred.h:9-42): src [nch, n] = the slot-0 / slot-1 channel's mean-removed samples, range4 =
+        (r0.lo, r0.hi, r1.lo, r1.hi); returns (pd, p_lpc, p_lms), each [nch, n] by predictor slot."""
+        a = np.ascontiguousarray(src, np.int32)
+        nch, n = a.shape
+        r4 = np.ascontiguousarray(range4, np.int32)
+        pd = np.zeros((nch, n)); pl = np.zeros((nch, n)); pm = np.zeros((nch, n))
+        self._chk(self.lib.sacamd_predictor_streams(self.h, nch, _vp(a[0]), _vp(a[1]) if nch == 2 else None, n, _vp(r4), byref(tp),
+                                                    _vp(pd), _vp(pl), _vp(pm)))
+        return pd, pl, pm
 
     def debug_bitplane(self, s2u, maxbpn) -> bytes:
         u = np.ascontiguousarray(s2u, np.int32)

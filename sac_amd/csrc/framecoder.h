@@ -16,9 +16,10 @@
 // predictor stages chase each other sample by sample, include/sac_amd.h); Decode() runs it, Unpredict() publishes `samples`.
 // Errors: the reference prints and continues or terminates; here every failure throws std::runtime_error with
 // sacamd_last_error() (never across the C ABI, which returns codes).
-// Not mirrored: Predictor (libsac/pred.h:9-42) -- its per-sample predict()/update() protocol is what the stage kernels
-// replace; the parity tap sacamd_debug_predict exposes its streams.
+// Predictor (libsac/pred.h:9-42) is mirrored in predictor.h (round 5: the encoder-side protocol, replayed from whole-frame GPU
+// streams); FrameCoder::SetParam (libsac.cpp:37-92) below builds its tparam from a profile as the reference does.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -29,6 +30,7 @@
 #include <vector>
 
 #include "../../include/sac_amd.h"
+#include "predictor.h"
 
 namespace sacamd {
 
@@ -89,6 +91,34 @@ class FrameCoder {
     c.fraction = cfg.ocfg.fraction; c.maxnfunc = cfg.ocfg.maxnfunc; c.num_threads = cfg.ocfg.num_threads; c.sigma = cfg.ocfg.sigma;
     c.optk = cfg.ocfg.optk; c.optimize_cost = (int)cfg.ocfg.optimize_cost; c.optimize_search = (int)cfg.ocfg.optimize_search;
     return c;
+  }
+
+  // FrameCoder::SetParam (libsac.cpp:37-92): profile -> Predictor::tparam (k = optk while optimising, 1 for the final pass / decoder)
+  static void SetParam(Predictor::tparam &param, const SacProfile &profile, bool optimize, int optk = 4) {
+    auto G = [&](std::size_t i) { return (double)profile.Get(i); };
+    auto R = [&](std::size_t i) { return (int)std::round((double)profile.Get(i)); };
+    param.k = optimize ? optk : 1;
+    param.lambda0 = G(0); param.ols_nu0 = G(1);
+    param.vn0 = {R(28), R(29), R(30), R(37)};
+    param.vn1 = {R(31), R(32), R(33), R(38)};
+    param.vmu0 = {G(2) / double(param.vn0[0]), G(3) / double(param.vn0[1]), G(4) / double(param.vn0[2]), G(5) / double(param.vn0[3])};
+    param.vmudecay0 = {G(6), G(39), G(46), G(47)};
+    param.vpowdecay0 = {G(7), G(8), G(50), G(51)};
+    param.mu_mix0 = G(10); param.mu_mix_beta0 = G(11);
+    param.lambda1 = G(12); param.ols_nu1 = G(13);
+    param.vmu1 = {G(14) / double(param.vn1[0]), G(15) / double(param.vn1[1]), G(16) / double(param.vn1[2]), G(17) / double(param.vn1[3])};
+    param.vmudecay1 = {G(18), G(40), G(48), G(49)};
+    param.vpowdecay1 = {G(19), G(20), G(21), G(52)};
+    param.mu_mix1 = G(22); param.mu_mix_beta1 = G(23);
+    param.nA = R(24); param.nB = R(25); param.nS0 = R(26); param.nS1 = R(27); param.nM0 = R(9);
+    param.beta_sum0 = G(34); param.beta_pow0 = G(35); param.beta_add0 = G(36);
+    param.beta_sum1 = G(53); param.beta_pow1 = G(54); param.beta_add1 = G(55);
+    param.proj_alpha0 = G(56); param.proj_alpha1 = G(57);
+    param.lm_n = R(41); param.lm_alpha = G(42);
+    param.bias_mu0 = G(43); param.bias_mu1 = G(44);
+    param.bias_scale0 = param.bias_scale1 = R(45);
+    param.ch_ref = 0;
+    if (param.nS1 < 0) { param.nS1 = -param.nS1; param.ch_ref = 1; }
   }
 
   FrameCoder(int numchannels, int framesize, const tsac_cfg &sac_cfg, int device = 0)

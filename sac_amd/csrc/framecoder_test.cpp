@@ -5,6 +5,9 @@
 //   framecoder_test <in.i32 planar [nframes][nch][n]> <nch> <n> <framesize> <optimize> <fraction> <maxnfunc> <num_threads> <sigma> <out.rec> [reset=1 [nframes=1]]
 // With nframes > 1 the ONE FrameCoder encodes the frames one after the other and writes their records back to back, so that
 // with reset=0 (the reference's default) each search starts from the previous frame's optimum (libsac.cpp:461-466).
+#include <climits>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -35,8 +38,60 @@ static int decode_main(int argc, char **argv) {
   return 0;
 }
 
+// --predictor: FrameCoder::PredictFrame's loop (libsac.cpp:95-141) over sacamd::Predictor (predictor.h), line for line: SetParam,
+// Range r0 / r1 from the frame statistics (un-swapped), fillbuf_ch0 / fillbuf_ch1 / predict / update in the reference's stereo
+// schedule, eprocess's rounding and clamp.
+//   framecoder_test --predictor <in.i32 planar MEAN-REMOVED [nch][total]> <nch> <total> <from> <numsamples> <coefs.f32 [58]> <optimize> <min0> <max0> <min1> <max1> <out.bin>
+// out.bin: per file channel the residuals int32 [numsamples], then per file channel the predictions pd as doubles [numsamples]
+static int predictor_main(int argc, char **argv) {
+  if (argc != 14) { std::fprintf(stderr, "usage: framecoder_test --predictor in.i32 nch total from numsamples coefs.f32 optimize min0 max0 min1 max1 out.bin\n"); return 2; }
+  const int numchannels_ = std::atoi(argv[3]), total = std::atoi(argv[4]), from = std::atoi(argv[5]), numsamples = std::atoi(argv[6]);
+  const bool optimize = std::atoi(argv[8]) != 0;
+  struct { int minval, maxval; } framestats[2] = {{std::atoi(argv[9]), std::atoi(argv[10])}, {std::atoi(argv[11]), std::atoi(argv[12])}};
+  try {
+    std::vector<std::vector<int32_t>> samples(numchannels_, std::vector<int32_t>(total)), error(numchannels_, std::vector<int32_t>(numsamples));
+    std::vector<std::vector<double>> pds(numchannels_, std::vector<double>(numsamples));
+    { std::ifstream in(argv[2], std::ios::binary); for (auto &v : samples) in.read(reinterpret_cast<char *>(v.data()), sizeof(int32_t) * (size_t)total); if (!in) throw std::runtime_error("short input"); }
+    sacamd::SacProfile profile; profile.LoadBaseProfile();
+    { std::ifstream in(argv[7], std::ios::binary); std::vector<float> g(profile.get_size()); in.read(reinterpret_cast<char *>(g.data()), sizeof(float) * g.size()); if (!in) throw std::runtime_error("short profile");
+      for (size_t i = 0; i < g.size(); i++) profile.coefs[i].vdef = g[i]; }
+    using sacamd::Predictor; using sacamd::Range;
+    Predictor::tparam param;
+    sacamd::FrameCoder::SetParam(param, profile, optimize);
+    Range r0{framestats[0].minval, framestats[0].maxval};
+    Range r1 = r0; if (numchannels_ == 2) r1 = {framestats[1].minval, framestats[1].maxval};
+    Predictor pr(r0, r1, param, numsamples);
+    auto eprocess = [&](int ch_p, int ch, int32_t val, int idx) {
+      double pd = pr.predict(ch_p);
+      const double rd = std::round(pd);
+      int32_t pi = (rd >= -2147483648.0 && rd < 2147483648.0) ? (int32_t)rd : INT32_MIN;      // (int32_t)std::round(pd) as the x86-64 reference converts it
+      pi = pi < framestats[ch].minval ? framestats[ch].minval : (pi > framestats[ch].maxval ? framestats[ch].maxval : pi);
+      error[ch][idx] = val - pi; pds[ch][idx] = pd;
+      pr.update(ch_p, val);
+    };
+    if (numchannels_ == 1) {
+      const auto *src = &samples[0][from];
+      for (int idx = 0; idx < numsamples; idx++) { pr.fillbuf_ch0(src, idx, src, idx); eprocess(0, 0, src[idx], idx); }
+    } else {
+      const int ch0 = param.ch_ref, ch1 = 1 - ch0;
+      const auto *src0 = &samples[ch0][from];
+      const auto *src1 = &samples[ch1][from];
+      int idx0 = 0, idx1 = 0;
+      while (idx0 < numsamples || idx1 < numsamples) {
+        if (idx0 < numsamples) { pr.fillbuf_ch0(src0, idx0, src1, idx1); eprocess(0, ch0, src0[idx0], idx0); idx0++; }
+        if (idx0 >= param.nS1) { pr.fillbuf_ch1(src0, src1, idx1, numsamples); eprocess(1, ch1, src1[idx1], idx1); idx1++; }
+      }
+    }
+    std::ofstream out(argv[13], std::ios::binary);
+    for (auto &v : error) out.write(reinterpret_cast<const char *>(v.data()), sizeof(int32_t) * v.size());
+    for (auto &v : pds) out.write(reinterpret_cast<const char *>(v.data()), sizeof(double) * v.size());
+  } catch (const std::exception &e) { std::fprintf(stderr, "framecoder_test: %s\n", e.what()); return 1; }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && std::string(argv[1]) == "--decode") return decode_main(argc, argv);
+  if (argc > 1 && std::string(argv[1]) == "--predictor") return predictor_main(argc, argv);
   if (argc < 11 || argc > 13) { std::fprintf(stderr, "usage: framecoder_test in.i32 nch n framesize optimize fraction maxnfunc num_threads sigma out.rec [reset [nframes]]\n"); return 2; }
   const int nch = std::atoi(argv[2]), n = std::atoi(argv[3]), framesize = std::atoi(argv[4]);
   sacamd::FrameCoder::tsac_cfg cfg;

@@ -119,7 +119,7 @@ struct sacamd_ctx {
   DevBuf<WorkItem> d_items;
   DevBuf<int> d_idx, d_err, d_pred, d_n, d_hist, d_nf;   // d_nf: per work-item "prediction not finite" flags of the last run_predict
   std::vector<int> h_nf;
-  DevBuf<double> d_tab, d_p, d_q, d_cost;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
+  DevBuf<double> d_tab, d_p, d_q, d_cost, d_pd;       // d_p: OLS output (p_lpc), d_q: cascade output (p_lpc + p_lms)
   DevBuf<long long> d_off, d_hoff;
   // final pass products (per frame, channel): offsets (f*nch+ch)*ch_stride
   DevBuf<int> d_ferr, d_fpred, d_fs2u, d_fs2u_map, d_maxbpn;
@@ -640,7 +640,7 @@ void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start
 }  // namespace
 
 // ================================================================== context
-API int sacamd_abi_version(void) { return 4; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*); 4: the gather's first all-gather carries 4 words per rank (ranks of different builds must not meet), sacamd_debug_libm
+API int sacamd_abi_version(void) { return 5; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*); 4: the gather's first all-gather carries 4 words per rank (ranks of different builds must not meet), sacamd_debug_libm
 
 API void sacamd_default_cfg(sacamd_cfg *cfg) {
   std::memset(cfg, 0, sizeof(*cfg));
@@ -707,7 +707,7 @@ API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c->ev_epoch) (void)hipEventDestroy(c->ev_epoch);
   c->d_pcm.release(); c->d_nsamp.release(); c->d_raw32.release(); c->d_plan_pcm.release(); c->d_raw16.release(); c->d_frame_off.release();
   c->d_stats.release(); c->d_used.release(); c->d_items.release(); c->d_idx.release(); c->d_err.release();
-  c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release();
+  c->d_pred.release(); c->d_nf.release(); c->d_n.release(); c->d_hist.release(); c->d_tab.release(); c->d_p.release(); c->d_q.release(); c->d_olskeep.release(); c->d_cost.release(); c->d_pd.release();
   c->d_off.release(); c->d_hoff.release(); c->d_ferr.release(); c->d_fpred.release(); c->d_fs2u.release(); c->d_fs2u_map.release();
   c->d_maxbpn.release(); c->d_laplace.release(); c->d_inv.release(); c->d_fwd.release(); c->d_cstate.release();
   c->d_cout.release(); c->d_clen.release(); c->d_jobs.release(); c->d_ccompact.release(); c->d_cat.release();
@@ -997,6 +997,48 @@ API int sacamd_get_residuals(sacamd_ctx *c, int frame, int32_t *error, int32_t *
 }
 
 // ================================================================== parity taps
+namespace {
+// the three stages of `items` (all with the window length n) one after the other, so that every stage's stream can be handed out:
+// p_lpc, p_lpc + p_lms, residual / rounded prediction and (pd) the bias stage's prediction before rounding; outputs [channel][n]
+int run_items_staged(sacamd_ctx *c, std::vector<WorkItem> &items, int n, bool latency_bound, double *plpc, double *psum, int32_t *err, int32_t *pred, double *pd) {
+  const int count = (int)items.size();
+  long long tot_tab = 0;
+  for (auto &it : items) {
+    long long e = it.off_tab;
+    for (int s = 0; s < 4; s++) e += 2LL * it.p.vn[s];
+    if (it.off_tabc >= 0) e = std::max(e, it.off_tabc + canon_tab_doubles(canon_rounds_of_class(it.lms_class)));
+    tot_tab = std::max(tot_tab, e);
+  }
+  HIPCHK(c, c->d_items.ensure(count)); HIPCHK(c, c->d_p.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_q.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_err.ensure((size_t)n * count + 512));
+  HIPCHK(c, c->d_pred.ensure((size_t)n * count + 512)); if (pd) HIPCHK(c, c->d_pd.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16)); HIPCHK(c, c->d_idx.ensure(count + 16));
+  HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
+  launch_tables(c->stream, c->d_items.p, count, c->d_tab.p);
+  for (int i = 0; i < count; i++) {
+    HIPCHK(c, hipMemcpyAsync(c->d_idx.p, &i, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { Span sp(c, FAM_OLS); launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p, latency_bound); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (plpc) HIPCHK(c, hipMemcpy(plpc + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    { Span sp(c, FAM_LMS);
+      LmsRingCap rc; for (int q = 0; q < 4; q++) rc.c[q] = items[i].p.vn[q] + 1;
+      launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, rc, view(c), c->d_tab.p, c->d_p.p, c->d_q.p); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_q.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  { Span sp(c, FAM_BIAS); launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, c->d_pred.p, nullptr, pd ? c->d_pd.p : nullptr); }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  collect_spans(c);
+  HIPCHK(c, hipGetLastError());
+  for (int i = 0; i < count; i++) {
+    if (err) HIPCHK(c, hipMemcpy(err + (size_t)items[i].ch_self * n, c->d_err.p + items[i].off_err, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (pred) HIPCHK(c, hipMemcpy(pred + (size_t)items[i].ch_self * n, c->d_pred.p + items[i].off_err, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (pd) HIPCHK(c, hipMemcpy(pd + (size_t)items[i].ch_self * n, c->d_pd.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+}  // namespace
+
 API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int start, int n, int optimize, int optk,
                              double *plpc, double *psum, int32_t *err, int32_t *pred) {
   if (!c || !coefs || frame < 0 || frame >= c->nframes) return SACAMD_ERR_ARG;
@@ -1007,40 +1049,7 @@ API int sacamd_debug_predict(sacamd_ctx *c, int frame, const float *coefs, int s
   std::vector<WorkItem> items;
   int r = build_items(c, cands, items);
   if (r) return r;
-  // stage by stage so the OLS stream can be captured before the cascade overwrites it
-  const int count = (int)items.size();
-  long long tot_tab = 0;
-  for (auto &it : items) {
-    long long e = it.off_tab;
-    for (int s = 0; s < 4; s++) e += 2LL * it.p.vn[s];
-    if (it.off_tabc >= 0) e = std::max(e, it.off_tabc + canon_tab_doubles(canon_rounds_of_class(it.lms_class)));
-    tot_tab = std::max(tot_tab, e);
-  }
-  HIPCHK(c, c->d_items.ensure(count)); HIPCHK(c, c->d_p.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_q.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_err.ensure((size_t)n * count + 512));
-  HIPCHK(c, c->d_pred.ensure((size_t)n * count + 512)); HIPCHK(c, c->d_tab.ensure((size_t)tot_tab + 16)); HIPCHK(c, c->d_idx.ensure(count + 16));
-  HIPCHK(c, hipMemcpyAsync(c->d_items.p, items.data(), sizeof(WorkItem) * count, hipMemcpyHostToDevice, c->stream));
-  launch_tables(c->stream, c->d_items.p, count, c->d_tab.p);
-  for (int i = 0; i < count; i++) {
-    HIPCHK(c, hipMemcpyAsync(c->d_idx.p, &i, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    { Span sp(c, FAM_OLS); launch_ols(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].ols_class, view(c), c->d_p.p, !optimize); }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (plpc) HIPCHK(c, hipMemcpy(plpc + (size_t)items[i].ch_self * n, c->d_p.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    { Span sp(c, FAM_LMS);
-      LmsRingCap rc; for (int q = 0; q < 4; q++) rc.c[q] = items[i].p.vn[q] + 1;
-      launch_lms(c->stream, c->d_items.p, c->d_idx.p, 1, items[i].lms_class, rc, view(c), c->d_tab.p, c->d_p.p, c->d_q.p); }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (psum) HIPCHK(c, hipMemcpy(psum + (size_t)items[i].ch_self * n, c->d_q.p + items[i].off_p, sizeof(double) * n, hipMemcpyDeviceToHost));
-  }
-  { Span sp(c, FAM_BIAS); launch_bias(c->stream, c->d_items.p, count, view(c), c->d_stats.p, c->nch, c->d_q.p, c->d_err.p, c->d_pred.p, nullptr); }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  collect_spans(c);
-  HIPCHK(c, hipGetLastError());
-  for (int i = 0; i < count; i++) {
-    if (err) HIPCHK(c, hipMemcpy(err + (size_t)items[i].ch_self * n, c->d_err.p + items[i].off_err, sizeof(int) * n, hipMemcpyDeviceToHost));
-    if (pred) HIPCHK(c, hipMemcpy(pred + (size_t)items[i].ch_self * n, c->d_pred.p + items[i].off_err, sizeof(int) * n, hipMemcpyDeviceToHost));
-  }
-  return 0;
+  return run_items_staged(c, items, n, !optimize, plpc, psum, err, pred, nullptr);
 }
 
 API int sacamd_debug_cost(sacamd_ctx *c, int kind, const int32_t *err, int n, double *cost) {
@@ -1245,6 +1254,69 @@ int guarded(sacamd_ctx *c, const char *what, F &&f) {
   }
 }
 }  // namespace
+// ================================================================== Predictor surface (libsac/pred.h:9-42)
+// The streams a Predictor(r0, r1, tparam) produces when it is driven over a frame the way FrameCoder::PredictFrame drives it
+// (libsac.cpp:113-141): what predict(slot) returns at every sample, and p_lpc / p_lms behind it.  src0 / src1 are the (mean-removed)
+// samples of the slot-0 / slot-1 channel as the caller hands them to fillbuf_ch0 / fillbuf_ch1; nch == 1: src1 is ignored.
+API int sacamd_predictor_streams(sacamd_ctx *c, int nch, const int32_t *src0, const int32_t *src1, int numsamples, const int32_t *range4,
+                                 const sacamd_pred_tparam *tp, double *pd, double *p_lpc, double *p_lms) {
+  if (!c || !src0 || !tp || !range4 || nch < 1 || nch > 2 || (nch == 2 && !src1) || numsamples < 1) return SACAMD_ERR_ARG;
+  if (nch != c->nch || numsamples > c->max_framesize) return fail(c, SACAMD_ERR_ARG, "predictor streams: channel count / frame length outside the context's");
+  return guarded(c, "sacamd_predictor_streams", [&]() -> int {
+    HIPCHK(c, hipSetDevice(c->device));
+    // stage the frame as it is (no analyse: the Predictor sees mean-removed samples and takes its clamp ranges as arguments)
+    c->eval_cache.clear(); c->ols_kept.clear(); c->ols_keep_len = 0;
+    c->nframes = 1; c->framesize = numsamples; c->nsamp.assign(1, numsamples); c->raw_kind = 0;
+    c->analysed = c->final_done = c->encoded = false;
+    c->h_stats.assign((size_t)nch, FrameStatsD{0, 0, 0, numsamples});
+    for (int ch = 0; ch < nch; ch++) { c->h_stats[ch].minval = range4[2 * ch]; c->h_stats[ch].maxval = range4[2 * ch + 1]; }
+    HIPCHK(c, hipMemcpyAsync(c->d_stats.p, c->h_stats.data(), sizeof(FrameStatsD) * nch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pcm.p, src0, sizeof(int) * (size_t)numsamples, hipMemcpyHostToDevice, c->stream));
+    if (nch == 2) HIPCHK(c, hipMemcpyAsync(c->d_pcm.p + c->ch_stride, src1, sizeof(int) * (size_t)numsamples, hipMemcpyHostToDevice, c->stream));
+    std::vector<WorkItem> items;
+    long long off_p = 0, off_tab = 0;
+    for (int slot = 0; slot < nch; slot++) {
+      WorkItem it;
+      std::memset(&it, 0, sizeof(it));
+      it.frame = 0; it.slot = slot; it.ch_self = slot; it.ch_other = nch == 2 ? 1 - slot : 0; it.start = 0; it.n = numsamples;
+      ChanParam &p = it.p;
+      const int nS1 = tp->nS1 < 0 ? -tp->nS1 : tp->nS1;
+      p.k = tp->k < 1 ? 1 : tp->k;
+      if (slot == 0) {                                             // Predictor::Predictor, pred.cpp:4-15; fillbuf_ch0, :17-23
+        p.a = tp->nA; p.b = tp->nM0; p.c = 0; p.du = nch == 2 ? ((nS1 > 1 ? nS1 : 1) - 1) : 0;
+        p.lambda = tp->lambda0; p.nu_eff = (1.0 - tp->lambda0) * tp->ols_nu0; p.beta_sum = tp->beta_sum0; p.beta_pow = tp->beta_pow0; p.beta_add = tp->beta_add0;
+        for (int s = 0; s < 4; s++) { p.vn[s] = tp->vn0[s]; p.vmu[s] = tp->vmu0[s]; p.vmudecay[s] = tp->vmudecay0[s]; p.vpowdecay[s] = tp->vpowdecay0[s]; }
+        p.mu_mix = tp->mu_mix0; p.mu_mix_beta = tp->mu_mix_beta0; p.proj_alpha = tp->proj_alpha0; p.bias_mu = tp->bias_mu0; p.bias_scale = tp->bias_scale0;
+      } else {                                                     // fillbuf_ch1, pred.cpp:25-31
+        p.a = tp->nB; p.b = tp->nS0; p.c = nS1; p.du = 0;
+        p.lambda = tp->lambda1; p.nu_eff = (1.0 - tp->lambda1) * tp->ols_nu1; p.beta_sum = tp->beta_sum1; p.beta_pow = tp->beta_pow1; p.beta_add = tp->beta_add1;
+        for (int s = 0; s < 4; s++) { p.vn[s] = tp->vn1[s]; p.vmu[s] = tp->vmu1[s]; p.vmudecay[s] = tp->vmudecay1[s]; p.vpowdecay[s] = tp->vpowdecay1[s]; }
+        p.mu_mix = tp->mu_mix1; p.mu_mix_beta = tp->mu_mix_beta1; p.proj_alpha = tp->proj_alpha1; p.bias_mu = tp->bias_mu1; p.bias_scale = tp->bias_scale1;
+      }
+      p.n_ols = p.a + p.b + p.c; p.lm_n = tp->lm_n; p.lm_alpha = tp->lm_alpha;
+      p.lo = range4[2 * slot]; p.hi = range4[2 * slot + 1]; p.out_lo = p.lo; p.out_hi = p.hi;
+      if (p.n_ols < 1 || p.n_ols > 96) return fail(c, SACAMD_ERR_ARG, "OLS order outside [1,96]");
+      if (p.lm_n < 1 || p.lm_n > 10) return fail(c, SACAMD_ERR_ARG, "RLS order outside [1,10]");
+      for (int s = 0; s < 4; s++)
+        if (p.vn[s] < 1 || p.vn[s] > (8192 >> s)) return fail(c, SACAMD_ERR_ARG, "NLMS stage length outside the profile box");
+      it.ols_class = 0;
+      while (p.n_ols > kOlsClassMax[it.ols_class]) it.ols_class++;
+      it.lms_class = lms_class_for(p.vn, /*canon=*/true);          // the reference's summation order whatever k
+      it.off_p = off_p; it.off_pin = off_p; it.off_err = off_p; it.off_tab = off_tab; it.off_tabc = -1;
+      off_p += numsamples;
+      for (int s = 0; s < 4; s++) off_tab += 2LL * p.vn[s];
+      if (it.lms_class >= kLmsCanonFirst && it.lms_class < kLmsCanon3First) { it.off_tabc = off_tab; off_tab += canon_tab_doubles(canon_rounds_of_class(it.lms_class)); }
+      items.push_back(it);
+    }
+    std::vector<double> psum(p_lms ? (size_t)nch * numsamples : 0), pl(p_lms && !p_lpc ? (size_t)nch * numsamples : 0);
+    double *plpc_out = p_lpc ? p_lpc : (p_lms ? pl.data() : nullptr);
+    int r = run_items_staged(c, items, numsamples, /*latency_bound=*/true, plpc_out, p_lms ? psum.data() : nullptr, nullptr, nullptr, pd);
+    if (r) return r;
+    if (p_lms) for (size_t i = 0; i < psum.size(); i++) p_lms[i] = psum[i] - plpc_out[i];   // (what the cascade added: reported, not used for parity -- pd and p_lpc are the exact streams)
+    return 0;
+  });
+}
+
 API int sacamd_analyse(sacamd_ctx *c, const sacamd_cfg *cfg) {
   return guarded(c, "sacamd_analyse", [&] { return analyse_body(c, cfg); });
 }

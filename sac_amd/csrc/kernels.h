@@ -31,7 +31,8 @@ int lms_max_wg_per_cu(int lms_class);          // register-file bound on residen
 void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, int lms_class, LmsRingCap rc, PcmView v,
                 const double *d_tab, const double *d_p /*p_lpc in*/, double *d_q /*p_lpc+p_lms out*/);
 void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
-                 const double *d_p, int *d_err, int *d_pred /*nullable*/, int *d_nonfinite /*[count]: set to 1 where the prediction was not finite*/);
+                 const double *d_p, int *d_err, int *d_pred /*nullable*/, int *d_nonfinite /*[count]: set to 1 where the prediction was not finite*/,
+                 double *d_pd = nullptr /*nullable: the bias stage's prediction before rounding (Predictor::predict), laid out like d_p*/);
 // ---- decoder: the three stages of every channel running side by side, two launches per group of frames (kernels_pred.hip)
 int dec_lms_class_for(const int *vn);            // cascade layout class of a decoder work-item (256-lane layouts only)
 size_t dec_cascade_lds_bytes(int lms_class, const LmsRingCap &rc);

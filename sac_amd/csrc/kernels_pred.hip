@@ -175,6 +175,12 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
   static const bool pack = [] { const char *e = std::getenv("SACAMD_OLS_PACK"); return !(e && e[0] == '0'); }();
   // 33..64 taps: the 2D-cyclic one-wave kernel (round 5) for search AND final pass; SACAMD_OLS_GRID=0 selects the round-4 kernels (A/B)
   static const bool grid = [] { const char *e = std::getenv("SACAMD_OLS_GRID"); return !(e && e[0] == '0'); }();
+  // 25..32 taps: the grid kernel as well (497 against 310 M item-steps/s saturated, 13.0 against 18.5 us per sample at k = 1); 17..24
+  // taps: the packed kernel in the search (778 against 737 M item-steps/s), the grid kernel in the final pass (9.2 against 11.8 us per
+  // sample) -- profiles/r05/ols_grid_short.txt.  SACAMD_OLS_GRID_SHORT=0 keeps the packed kernels (A/B).
+  static const bool grid_short = [] { const char *e = std::getenv("SACAMD_OLS_GRID_SHORT"); return !(e && e[0] == '0'); }();
+  if (grid && grid_short && ols_class == 2) { launch_ols_grid_c<4>(s, d_items, d_idx, count, v, d_p); return; }
+  if (grid && grid_short && ols_class == 1 && latency_bound) { launch_ols_grid_c<3>(s, d_items, d_idx, count, v, d_p); return; }
   if (grid && ols_class >= 3 && ols_class <= 6) {
     switch (ols_class) {
       case 3: launch_ols_grid_c<5>(s, d_items, d_idx, count, v, d_p); break;
@@ -365,7 +371,7 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
 constexpr int kBiasSlabStride = kBiasSlabDoubles + 1;   // odd stride: spread lanes over LDS banks
 
 __global__ __launch_bounds__(64) void k_bias(const WorkItem *items, int count, PcmView v, const FrameStatsD *stats, int nch,
-                                              const double *pbuf, int *errbuf, int *predbuf, int *nonfinite) {
+                                              const double *pbuf, int *errbuf, int *predbuf, int *nonfinite, double *pdbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= count) return;
@@ -374,14 +380,15 @@ __global__ __launch_bounds__(64) void k_bias(const WorkItem *items, int count, P
   const int *self = v.pcm + it.frame * v.frame_stride + it.ch_self * v.ch_stride + it.start;
   double *tables = reinterpret_cast<double *>(smem) + (size_t)threadIdx.x * kBiasSlabStride;
   const int mean = stats[it.frame * nch + it.ch_self].mean;
-  bias_stage(p, self, it.n, pbuf + it.off_p, mean, errbuf + it.off_err, predbuf ? predbuf + it.off_err : nullptr, tables, nonfinite ? nonfinite + i : nullptr);
+  bias_stage(p, self, it.n, pbuf + it.off_p, mean, errbuf + it.off_err, predbuf ? predbuf + it.off_err : nullptr, tables, nonfinite ? nonfinite + i : nullptr, nullptr,
+             pdbuf ? pdbuf + it.off_p : nullptr);
 }
 
 void launch_bias(hipStream_t s, const WorkItem *d_items, int count, PcmView v, const FrameStatsD *d_stats, int nch,
-                 const double *d_p, int *d_err, int *d_pred, int *d_nonfinite) {
+                 const double *d_p, int *d_err, int *d_pred, int *d_nonfinite, double *d_pd) {
   if (count <= 0) return;
   const size_t bytes = (size_t)64 * kBiasSlabStride * sizeof(double);
-  hipLaunchKernelGGL(k_bias, dim3((count + 63) / 64), dim3(64), bytes, s, d_items, count, v, d_stats, nch, d_p, d_err, d_pred, d_nonfinite);
+  hipLaunchKernelGGL(k_bias, dim3((count + 63) / 64), dim3(64), bytes, s, d_items, count, v, d_stats, nch, d_p, d_err, d_pred, d_nonfinite, d_pd);
 }
 
 // ------------------------------------------------------------------ decoder: the three stages of a channel side by side

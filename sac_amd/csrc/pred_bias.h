@@ -42,7 +42,7 @@ SA_HD int bias_unmap(const int *prefix, int pred, int merr) {
 // dec != null: decoder (FrameCoder::UnpredictFrame's dprocess, libsac.cpp:153-165): the sample is the prediction plus the
 // decoded residual (un-mapped first for mapped streams), written to dec->self_w and announced; `self` is not read.
 SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *psum, int mean,
-                      int *err, int *pred, double *tables, int *nonfinite = nullptr, const DecLink *dec = nullptr) {
+                      int *err, int *pred, double *tables, int *nonfinite = nullptr, const DecLink *dec = nullptr, double *pd_out = nullptr) {
   double *cnt = tables, *val = tables + kBiasCtx;
   for (int i = 0; i < kBiasCtx; i++) { cnt[i] = 4.0; val[i] = 0.0; }
   double *mixw = tables + 2 * kBiasCtx;    // [4][3]
@@ -80,6 +80,7 @@ SA_HD void bias_stage(const ChanParam &p, const int *self, int n, const double *
     double *mw = mixw + 3 * mix_ctx;
     const double pbias = dot_canon(pt, mw, 3);
     const double pd = px + pbias;
+    if (pd_out) pd_out[t] = pd;                      // Predictor::predict's return value (libsac/pred.cpp:33-38), before eprocess rounds it
     // eprocess (libsac.cpp:105-109)
     const int pi = clampi32(cvt_i32_x86(round(pd)), p.out_lo, p.out_hi);
     int v;

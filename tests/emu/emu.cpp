@@ -28,7 +28,7 @@ static void run_lms(const ChanParam &p, const double *sp, const double *tab, con
   delete ex;
 }
 
-static int g_ols_grid = 1;      // 33..64 taps: 1 = grid kernel (the launcher's choice since round 5), 0 = the row-per-lane / panel kernels
+static int g_ols_grid = 1;      // 17/25..64 taps: 1 = grid kernel (the launcher's choice since round 5), 0 = the row-per-lane / panel kernels
 API void emu_set_ols_grid(int on) { g_ols_grid = on; }
 
 // samples planar [nch][total] mean-removed; stats [nch][3] = {min,max,mean}
@@ -51,8 +51,8 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
 #define EMU_OLSP(NM) { std::vector<char> lds(ols_panel_lds_bytes(NM, 4)); ExecEmu<256> ex; ols_stage_panel<ExecEmu<256>, NM>(ex, p, self, other, n, pl, lds.data()); }
 #define EMU_OLSG(NBK) { std::vector<char> lds(OlsLdsGrid::bytes(8 * NBK), (char)0xFF); ExecEmu<64> ex; ols_stage_grid<ExecEmu<64>, NBK>(ex, p, self, other, n, pl, lds.data()); }
 #define EMU_OLS(NM) { std::vector<char> lds(OlsLdsFast::bytes(NM)); ExecEmu<64> ex; ols_stage_reg<ExecEmu<64>, NM>(ex, p, self, other, n, pl, lds.data()); }
-      if (g_ols_grid && p.n_ols > 32 && p.n_ols <= 64) {     // 2D-cyclic one-wave kernel (pred_ols_grid.h): search and final pass
-        if (p.n_ols <= 40) EMU_OLSG(5) else if (p.n_ols <= 48) EMU_OLSG(6) else if (p.n_ols <= 56) EMU_OLSG(7) else EMU_OLSG(8)
+      if (g_ols_grid && p.n_ols > (optimize ? 24 : 16) && p.n_ols <= 64) {     // 2D-cyclic one-wave kernel (pred_ols_grid.h), as the launcher: 25..64 taps, and 17..24 in the final pass
+        if (p.n_ols <= 24) EMU_OLSG(3) else if (p.n_ols <= 32) EMU_OLSG(4) else if (p.n_ols <= 40) EMU_OLSG(5) else if (p.n_ols <= 48) EMU_OLSG(6) else if (p.n_ols <= 56) EMU_OLSG(7) else EMU_OLSG(8)
       }
       else if (!optimize) {     // as the host (build_items): the final pass uses the 32 / 64 / 96-tap capacity classes only
         if (p.n_ols <= 32) EMU_OLS(32)

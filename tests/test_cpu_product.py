@@ -13,6 +13,7 @@ import pytest
 
 from golden_cases import trace_cases, trace_cases_r2
 from oracle_api import _vp, center_frame, frame_cfg
+from sac_amd.synth import synth_pcm
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -38,7 +39,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     import sac_amd.api as api
     assert sorted(api.ABI_SYMBOLS) == declared
-    assert lib.sacamd_abi_version() == api.ABI_VERSION == 4
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 5
     # without a GPU the context constructor must fail loudly (no CPU fallback)
     import torch
     if not torch.cuda.is_available():
@@ -154,6 +155,35 @@ def test_prediction_conversion_follows_the_x86_reference(emu, orc):
     rc = emu.emu_predict(2, n, _vp(np.ascontiguousarray(smp, np.int32)), _vp(np.ascontiguousarray(stats, np.int32)),
                          _vp(np.ascontiguousarray(prof, np.float32)), 0, n, 0, 4, _vp(plpc), _vp(psum), _vp(err), _vp(pred))
     assert rc == 0 and np.array_equal(err, oerr)
+
+
+@pytest.mark.parametrize("case", [(1, 17, 0, 0), (1, 24, 0, 1), (1, 25, 0, 1), (1, 32, 0, 0), (1, 32, 1, 1), (1, 32, 8, 0), (1, 32, 9, 1), (1, 32, 16, 0), (1, 32, 17, 1),
+                                  (1, 32, 24, 0), (1, 32, 25, 1), (1, 32, 32, 0), (1, 32, 32, 1), (2, 20, 13, 0), (2, 32, 29, 1), (2, 31, 30, 0)])
+def test_grid_ols_kernel_body_vs_oracle(emu, orc, case):
+    """pred_ols_grid.h (matrix 2D-cyclic over the lanes of one wave, backward solve as one row-broadcast pass over the linear
+    stream): p_lpc bit-identical to the oracle for every block count NB = 3 .. 8 incl. the class boundaries (17, 24 | 25, 32 | 33,
+    40 | 41 ... 64 taps), mono (nA + nM0) and stereo slot 1 (nB + nS0 + |nS1|, ch_ref swap), k = 1 (final pass) and k = optk."""
+    nch, a, b, opt = case
+    rng = np.random.default_rng(1000 * a + 10 * b + opt)
+    n = 700
+    raw = synth_pcm(n, nch, seed=77 + a + b, rate=8000)
+    smp, stats = center_frame(raw)
+    g = orc.profile()[:, 2].copy()
+    if nch == 1:
+        g[24] = a; g[9] = b
+    else:
+        g[24] = 12; g[9] = 0
+        g[25] = a; g[26] = b // 2; g[27] = (b - b // 2) * (-1 if opt else 1)       # slot 1: nB + nS0 + |nS1| taps; nS1 < 0: ch_ref = 1
+    g[0] = rng.uniform(0.99, 0.9999); g[12] = rng.uniform(0.99, 0.9999); g[1] = rng.uniform(1, 100); g[13] = rng.uniform(1, 100)
+    pd, plpc, plms, oerr = orc.predict_trace(smp, stats, g, 0, n, opt)
+    pl = np.zeros((nch, n)); ps = np.zeros((nch, n)); err = np.zeros((nch, n), np.int32); pred = np.zeros((nch, n), np.int32)
+    emu.emu_set_ols_grid(1)
+    rc = emu.emu_predict(nch, n, _vp(np.ascontiguousarray(smp, np.int32)), _vp(np.ascontiguousarray(stats, np.int32)), _vp(np.ascontiguousarray(g, np.float32)),
+                         0, n, opt, 4, _vp(pl), _vp(ps), _vp(err), _vp(pred))
+    assert rc == 0
+    assert np.array_equal(pl.view(np.uint64), plpc.view(np.uint64))
+    if not opt:
+        assert np.array_equal(err, oerr)
 
 
 def test_host_dds_driver_matches_reference_search(emu, golden):

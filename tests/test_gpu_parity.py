@@ -28,7 +28,7 @@ def gpu_cfg(api, cfg):
 
 def test_library_is_the_hip_one(api):
     lib = api.load_library()
-    assert lib.sacamd_abi_version() == api.ABI_VERSION == 4
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 5
     ctx = api.Context(2, 1000, 1)   # fails loudly without a gfx950 device
     ctx.close()
     assert np.array_equal(api.default_profile(), np.load(__import__("os").path.join(
@@ -860,6 +860,57 @@ def test_gpu_decoder_at_the_profile_box_maximum(api):
     ctx.close()
     assert np.array_equal(pr[0], prof.astype(np.float32))
     assert np.array_equal(pcm[0], raw)
+
+
+@pytest.mark.parametrize("name", list(trace_cases(np.zeros((58, 3), np.float32)).keys()))
+def test_predictor_surface_streams_vs_golden(api, golden, name):
+    """Predictor surface (libsac/pred.h:9-42; C ABI sacamd_predictor_streams, class sacamd::Predictor in predictor.h): what
+    predict(slot) returns at every sample when PredictFrame (libsac.cpp:113-141) drives a Predictor built from SetParam's tparam
+    (:37-92) -- pd and p_lpc bit-identical to the genuine reference's traces, for k = 1 and k = optk alike (the surface always sums
+    in slmath::dot order), incl. the ch_ref swap (clamp ranges by slot, un-swapped), nS1 = 0, a window inside the frame, 64 / 96-tap
+    regressors and 8-bit material."""
+    raw = golden[f"trace/{name}/raw"]
+    coefs = np.ascontiguousarray(golden[f"trace/{name}/coefs"], np.float32)
+    _, _, opt, start, n = trace_cases(golden["profile"])[name]
+    smp, stats = center_frame(raw)
+    nch = smp.shape[0]
+    tp = api.tparam_from_profile(coefs, bool(opt), 4)
+    order = [tp.ch_ref, 1 - tp.ch_ref] if nch == 2 else [0]
+    src = np.ascontiguousarray(smp[order, start:start + n], np.int32)
+    st = np.asarray(stats, np.int32).reshape(-1, 3)
+    r4 = [st[0, 0], st[0, 1]] + ([st[1, 0], st[1, 1]] if nch == 2 else [st[0, 0], st[0, 1]])      # r0 / r1 = framestats[0] / [1], NOT swapped (libsac.cpp:99-102)
+    ctx = api.Context(nch, max(n, 16), 1)
+    pd, pl, pm = ctx.predictor_streams(src, r4, tp)
+    ctx.close()
+    want_pd, want_pl = golden[f"trace/{name}/pd"], golden[f"trace/{name}/plpc"]
+    for slot, ch in enumerate(order):
+        assert np.array_equal(pl[slot].view(np.uint64), want_pl[ch].view(np.uint64)), (name, slot)
+        assert np.array_equal(pd[slot].view(np.uint64), want_pd[ch].view(np.uint64)), (name, slot)
+
+
+@pytest.mark.parametrize("name", ["tr_s16_default_k1", "tr_s16_swap_k4", "tr_m16_rand_k1", "tr_s16_default_k4_window"])
+def test_predictor_class_in_predictframe_loop(api, golden, name, tmp_path):
+    """sacamd::Predictor (predictor.h) driven by sac_amd/framecoder_test --predictor, a compiled C++ program whose loop is
+    FrameCoder::PredictFrame's (libsac.cpp:95-141: SetParam, Range r0 / r1, fillbuf_ch0 / fillbuf_ch1 / predict / update in the
+    reference's stereo schedule, eprocess): residuals and predictions equal the genuine reference's traces."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sac_amd", "framecoder_test")
+    raw = golden[f"trace/{name}/raw"]
+    coefs = np.ascontiguousarray(golden[f"trace/{name}/coefs"], np.float32)
+    _, _, opt, start, n = trace_cases(golden["profile"])[name]
+    smp, stats = center_frame(raw)
+    nch, total = smp.shape
+    st = np.asarray(stats, np.int32).reshape(-1, 3)
+    fin = tmp_path / "in.i32"; np.ascontiguousarray(smp, np.int32).tofile(fin)
+    fco = tmp_path / "coefs.f32"; coefs.tofile(fco)
+    out = tmp_path / "out.bin"
+    subprocess.run([exe, "--predictor", str(fin), str(nch), str(total), str(start), str(n), str(fco), str(int(opt)), str(st[0, 0]), str(st[0, 1]),
+                    str(st[-1, 0]), str(st[-1, 1]), str(out)], check=True)
+    blob = out.read_bytes()
+    err = np.frombuffer(blob[: 4 * nch * n], np.int32).reshape(nch, n)
+    pd = np.frombuffer(blob[4 * nch * n:], np.float64).reshape(nch, n)
+    assert np.array_equal(pd.view(np.uint64), golden[f"trace/{name}/pd"].view(np.uint64))
+    assert np.array_equal(err, golden[f"trace/{name}/err"])
 
 
 def test_framecoder_wrapper_decode_side(api, golden, golden_r3, tmp_path):
