@@ -156,6 +156,8 @@ struct sacamd_ctx {
   DevBuf<double> d_olskeep;
   int ols_keep_len = 0;                       // doubles per kept stream (the search window)
   long long ols_stamp = 0, ols_kept_hits = 0, ols_leaders = 0;
+  // tracing: search cascade work (item-steps) by the 64-tap slots an item would need on ONE wave (sum over stages of ceil(n / 64)), bins of 4
+  double slot_hist[64] = {};
   bool ols_keep_on = false;                   // set by sacamd_evaluate around its run_predict call
   // timing events are recycled (no event creation on the per-generation path once the pool has warmed up)
   std::vector<hipEvent_t> ev_pool;
@@ -473,6 +475,16 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   // the reference's per-instance km >= kmax (pred/ols.cpp:46-55) only when every item of the launch has the same k
   for (int k = 0; k < 3; k++)
     for (int i : idx_ols[k]) if (items[i].p.k != items[idx_ols[k][0]].p.k) return fail(c, SACAMD_ERR_ARG, "packed OLS launch with mixed solve intervals k");
+  if (c->tracing && !want_pred) {
+    static FILE *dump = [] { const char *e = std::getenv("SACAMD_DUMP_VN"); return e ? std::fopen(e, "w") : nullptr; }();   // stage lengths of every search cascade item (layout design)
+    if (dump) { for (int i = 0; i < count; i++) std::fprintf(dump, "%d %d %d %d\n", items[i].p.vn[0], items[i].p.vn[1], items[i].p.vn[2], items[i].p.vn[3]); std::fflush(dump); }
+  }
+  if (c->tracing && !want_pred)
+    for (int i = 0; i < count; i++) {
+      const int *v = items[i].p.vn;
+      const int sl = (v[0] + 63) / 64 + (v[1] + 63) / 64 + (v[2] + 63) / 64 + (v[3] + 63) / 64;
+      c->slot_hist[std::min(sl / 4, 63)] += (double)items[i].n;
+    }
   auto taps = [&](int i) { const int *v = items[i].p.vn; return (long long)(v[0] + v[1] + v[2] + v[3]) * items[i].n; };
   auto olsw = [&](int i) { long long n = items[i].p.n_ols; return n * n * n / items[i].p.k * items[i].n; };
   std::vector<int> flat;
@@ -696,6 +708,15 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
 API void sacamd_ctx_destroy(sacamd_ctx *c) {
   if (c && c->tracing) std::fprintf(stderr, "[sacamd trace] search OLS streams: %lld distinct, %lld read from kept streams\n", c->ols_leaders, c->ols_kept_hits);
   if (!c) return;
+  if (c->tracing) {
+    double tot = 0; for (double v : c->slot_hist) tot += v;
+    if (tot > 0) {
+      std::fprintf(stderr, "[sacamd trace] search cascade item-steps by one-wave slot need (64 taps per slot; cumulative share):");
+      double cum = 0;
+      for (int b = 0; b < 64; b++) { cum += c->slot_hist[b]; if (c->slot_hist[b] > 0) std::fprintf(stderr, " <%d:%.3f", 4 * b + 4, cum / tot); }
+      std::fprintf(stderr, "\n");
+    }
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); collect_spans(c); }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -316,10 +316,7 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
 int lms_class_for(const int *vn, bool canon) {
   auto fits = [&](int nl, int c0, int c1, int c2, int c3) { return vn[0] <= c0 * nl && vn[1] <= c1 * nl && vn[2] <= c2 * nl && vn[3] <= c3 * nl; };
   if (canon) {
-    if (canon3_fits(vn, LmsP17::c0, 2)) return 10;
-    if (canon3_fits(vn, LmsP33::c0, 2)) return 11;
-    if (canon3_fits(vn, LmsP49::c0, 2)) return 12;
-    if (canon3_fits(vn, LmsP33::c0, 4)) return 13;
+    { const int c3 = canon3_class_for(vn); if (c3 >= 0) return c3; }      // lane-map layouts: chains fit the lanes, rings + tables one CU's LDS
     // beyond ~7.5 k taps: the round-2 systolic layouts
     if (fits(256, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 7;     // one round over the lanes
     if (fits(512, LmsK::c0, LmsK::c1, LmsK::c2, LmsK::c3)) return 8;     // two rounds

@@ -179,6 +179,20 @@ struct LmsLds {
 };
 
 
+// Lane-map layout (CANON 3) of an item with stage lengths vn: 10 / 11 / 12 = 17 / 33 / 49 positions per lane on 256 lanes, 13 = 33 on 512
+// lanes, -1 = none.  The chains must fit the lanes (canon3_fits) AND the item's rings, mirrors and lane-major mutab block one CU's
+// LDS: the 512-lane layout spends 68 KB on mutab alone and stops fitting near 7.5 k taps although its chains would hold 8.4 k (round 5:
+// the reference's sequential search picks such profiles; the launch used to fail with "invalid argument").
+SA_HD int canon3_class_for(const int *vn) {
+  const int rc[4] = {vn[0] + 1, vn[1] + 1, vn[2] + 1, vn[3] + 1};
+  constexpr size_t kLds = 160 * 1024;
+  if (canon3_fits(vn, 17, 2) && LmsLds<256, LmsClass<17, 0, 0, 0>, 3>::bytes(rc) <= kLds) return 10;
+  if (canon3_fits(vn, 33, 2) && LmsLds<256, LmsClass<33, 0, 0, 0>, 3>::bytes(rc) <= kLds) return 11;
+  if (canon3_fits(vn, 49, 2) && LmsLds<256, LmsClass<49, 0, 0, 0>, 3>::bytes(rc) <= kLds) return 12;
+  if (canon3_fits(vn, 33, 4) && LmsLds<512, LmsClass<33, 0, 0, 0>, 3>::bytes(rc) <= kLds) return 13;
+  return -1;
+}
+
 // tail of slmath::dot handled by std::transform_reduce (< 8 elements), operands through getters
 template <class A, class B>
 SA_HD double tr_dot_g(int n, A a, B b) {

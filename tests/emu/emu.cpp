@@ -79,10 +79,11 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     for (int t = 0; t < n; t++) ps[t] = pl[t];
     const int *vn = p.vn;
     const bool systolic = std::getenv("SACAMD_CANON_SYSTOLIC") && std::getenv("SACAMD_CANON_SYSTOLIC")[0] == '1';
-    if (!optimize && !systolic && canon3_fits(vn, 17, 2)) run_lms<LmsClass<17, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);       // as the launcher (lms_class_for): lane-map canonical layouts
-    else if (!optimize && !systolic && canon3_fits(vn, 33, 2)) run_lms<LmsClass<33, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);
-    else if (!optimize && !systolic && canon3_fits(vn, 49, 2)) run_lms<LmsClass<49, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);
-    else if (!optimize && !systolic && canon3_fits(vn, 33, 4)) run_lms<LmsClass<33, 0, 0, 0>, 512, 3>(p, sp, tab.data(), self, n, ps);
+    const int c3 = canon3_class_for(vn);
+    if (!optimize && !systolic && c3 == 10) run_lms<LmsClass<17, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);       // as the launcher (lms_class_for): lane-map canonical layouts
+    else if (!optimize && !systolic && c3 == 11) run_lms<LmsClass<33, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);
+    else if (!optimize && !systolic && c3 == 12) run_lms<LmsClass<49, 0, 0, 0>, 256, 3>(p, sp, tab.data(), self, n, ps);
+    else if (!optimize && !systolic && c3 == 13) run_lms<LmsClass<33, 0, 0, 0>, 512, 3>(p, sp, tab.data(), self, n, ps);
     else if (!optimize) {   // the systolic layouts of round 2: fallback for the largest profiles; the final pass sums in slmath::dot order
       // lane-major table copies as k_tables writes them for the canonical layouts (pred_tables.h)
       const int rounds = (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256) ? 1 : ((vn[0] <= 4608 && vn[1] <= 2560 && vn[2] <= 1536 && vn[3] <= 512) ? 2 : 4);
@@ -154,11 +155,20 @@ API int emu_ols_pack(int cls, int count, const int *nch, const int *total, const
 // cascade layout class the launcher picks for the final pass of an item with these stage lengths (kernels_pred.hip,
 // lms_class_for): 10..13 = lane-map layouts (J, lanes) = (17,256) (33,256) (49,256) (33,512); 9 = systolic fallback
 API int emu_canon_class(const int *vn) {
-  if (canon3_fits(vn, 17, 2)) return 10;
-  if (canon3_fits(vn, 33, 2)) return 11;
-  if (canon3_fits(vn, 49, 2)) return 12;
-  if (canon3_fits(vn, 33, 4)) return 13;
-  return 9;
+  const int c3 = canon3_class_for(vn);
+  return c3 >= 0 ? c3 : 9;
+}
+
+// LDS bytes the lane-map layout `cls` (10..13) asks for when it holds an item with stage lengths vn (the launcher's dynamic LDS size)
+API long emu_canon_lds_bytes(const int *vn, int cls) {
+  const int rc[4] = {vn[0] + 1, vn[1] + 1, vn[2] + 1, vn[3] + 1};
+  switch (cls) {
+    case 10: return (long)LmsLds<256, LmsClass<17, 0, 0, 0>, 3>::bytes(rc);
+    case 11: return (long)LmsLds<256, LmsClass<33, 0, 0, 0>, 3>::bytes(rc);
+    case 12: return (long)LmsLds<256, LmsClass<49, 0, 0, 0>, 3>::bytes(rc);
+    case 13: return (long)LmsLds<512, LmsClass<33, 0, 0, 0>, 3>::bytes(rc);
+    default: return -1;
+  }
 }
 
 // ---------------------------------------------------------------- coder

@@ -186,6 +186,27 @@ def test_grid_ols_kernel_body_vs_oracle(emu, orc, case):
         assert np.array_equal(err, oerr)
 
 
+def test_lane_map_layout_choice_respects_the_lds(emu):
+    """canon3_class_for (pred_lms.h): a lane-map layout is taken only if the item's rings + lane-major mutab block fit the 160 KB of
+    one CU's LDS (round 5: the 512-lane layout used to be chosen by its chains alone and asked for more); what no lane-map layout
+    can take goes to the systolic layout (9).  Property over the whole profile box + the cases that failed on the GPU."""
+    emu.emu_canon_lds_bytes.restype = ctypes.c_long
+    cls = lambda vn: emu.emu_canon_class((ctypes.c_int * 4)(*vn))
+    lds = lambda vn, c: emu.emu_canon_lds_bytes((ctypes.c_int * 4)(*vn), c)
+    rng = np.random.default_rng(11)
+    seen = set()
+    for _ in range(4000):
+        vn = (int(rng.integers(256, 8193)), int(rng.integers(32, 4097)), int(rng.integers(4, 2049)), int(rng.integers(2, 1025)))
+        c = cls(vn); seen.add(c)
+        assert c in (9, 10, 11, 12, 13)
+        if c != 9:
+            assert lds(vn, c) <= 160 * 1024, (vn, c)
+    assert seen == {9, 10, 11, 12, 13}
+    assert cls((1280, 256, 32, 4)) == 10 and cls((8192, 4096, 2048, 1024)) == 9
+    big = [vn for vn in ((6600, 300, 40, 8), (6900, 64, 8, 8), (7200, 32, 4, 2)) if cls(vn) == 13]
+    assert big and all(lds(vn, 13) <= 160 * 1024 for vn in big)
+
+
 def test_host_dds_driver_matches_reference_search(emu, golden):
     nd = 12
     lo = np.zeros(nd); hi = np.arange(1, nd + 1) * 1.0

@@ -221,6 +221,26 @@ def test_random_profiles_residuals(api, orc):
     ctx.close()
 
 
+def test_final_pass_layout_choice_respects_the_lds(api, orc):
+    """Final pass (k = 1, canonical order) of profiles whose chains would fit the 512-lane lane-map layout but whose rings + lane-major
+    mutab block exceed one CU's LDS (7.6 k .. 8.4 k taps): the launcher must fall back to the systolic layout instead of asking for
+    more than 160 KB (round 5: such a launch failed with "invalid argument" in the reference's sequential search at 256 frames).
+    Residuals and the bit-exact prediction sum equal the oracle's."""
+    P = orc.profile()
+    raw = synth_pcm(700, 2, 905, RATE)
+    smp, stats = center_frame(raw)
+    ctx = api.Context(2, FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    ctx.analyse(api.make_cfg("normal"))
+    for taps in ((8100, 300, 40, 8), (7700, 700, 64, 16), (7000, 1000, 300, 100)):
+        g = P[:, 2].copy()
+        g[28], g[29], g[30], g[37] = taps; g[31], g[32], g[33], g[38] = taps
+        want, _ = orc.predict_frame(smp, stats, g, 0, 700, 0)
+        _, _, err, _ = ctx.debug_predict(0, g.astype(np.float32), 0, 700, 0)
+        assert np.array_equal(err, want), taps
+    ctx.close()
+
+
 def test_full_size_roundtrip_property(api, orc):
     """BASELINE-size property: a 44.1 kHz stereo frame encoded on the GPU (--normal) decodes to the
     input with the CPU decoder (encode -> decode round trip), and bps is sane."""
