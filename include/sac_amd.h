@@ -15,11 +15,23 @@
  * take turns with their search phases (one search saturates the chip).  There is no CPU fallback: if no
  * gfx950 device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
  *
- * Environment switches (read once per process).  SACAMD_TRACE=1 prints every predictor launch with its duration and start
- * offset.  SACAMD_OLS_FINAL_PANEL=0 runs the final pass's 33..64-tap items on the one-wave OLS kernel.  Parity taps:
- * SACAMD_CODER_SERIAL=1 runs the coder's decision chain on one lane (the body the CPU emulation runs).  Decoder:
- * SACAMD_DEC_SINGLE=1 every frame group as one launch (the fallback form); SACAMD_DEC_ZERO=0 skips zeroing the decoder's planes.
- * (The scheduling experiments of rounds 2-3 that measured as losses -- DESIGN.md 9 -- are no longer selectable.)
+ * Hardware queues: HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read at the process's first HIP call.  The
+ * library sets it to 24 when it is loaded unless the environment already has it; sacamd_ctx_create refuses (SACAMD_ERR_STATE, message on
+ * stderr) a value below 16 unless SACAMD_ALLOW_FEW_QUEUES=1.  A host that has initialised HIP before loading the library exports it itself.
+ *
+ * Environment switches (read once per process; every one is an A/B or diagnostic aid, the defaults are the product):
+ *   SACAMD_TRACE=1             every predictor launch with its duration and start offset on stderr; at context destruction the search
+ *                              cascade's work by tap count.  SACAMD_DUMP_VN=file (with TRACE) writes the stage lengths of every search item.
+ *   SACAMD_OLS_GRID=0          33..64-tap OLS items on the round-4 kernels (one-wave row layout in the search, four-wave panel kernel in
+ *                              the final pass: SACAMD_OLS_FINAL_PANEL=0 keeps the one-wave kernel there too) instead of k_ols_grid.
+ *   SACAMD_OLS_GRID_SHORT=0    17..32-tap items on the packed kernels everywhere.   SACAMD_OLS_PACK=0: one item per wave up to 32 taps.
+ *   SACAMD_FAST_OLS=n          search: OLS classes [0, n) form the cascade's first launch group (default 3).
+ *   SACAMD_FINAL_GROUPS=1      final pass: one cascade launch group per OLS class (measured as a loss).
+ *   SACAMD_CODER_SERIAL=1      parity tap: the coder's decision chain on one lane (the body the CPU emulation runs).
+ *   SACAMD_DEC_SINGLE=1        decoder: every frame group as one cooperative launch (the fallback form).  SACAMD_DEC_ZERO=0 skips zeroing its planes.
+ *   SACAMD_ALLOW_FEW_QUEUES=1  see above.
+ * (Rounds 2-4 had more: tail priorities, chase mode, pipelining, the panel-kernel slot budget and head start -- all measured, documented in
+ *  DESIGN.md 9 and removed.)
  */
 #ifndef SAC_AMD_H
 #define SAC_AMD_H

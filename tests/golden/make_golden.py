@@ -145,6 +145,32 @@ def main_r5():
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def main_r6(only=None):
+    """tests/golden/ref_golden_r6.npz (round 5): BASELINE configs[3] / [4] with the presets' FULL evaluation counts (--veryhigh
+    E = 300, --best E = 1000), one 882 000-sample frame each, genuine reference objects with the reference's own threading for
+    --opt-cfg=dds,8 (Opt::eval_points_mt on 8 threads: same results as serial evaluation, an eighth of the wall time)."""
+    import hashlib, time
+    from golden_cases import FULL_FRAMESIZE, config34_full_cases
+    R = Checker("ref")
+    R.lib.ref_set_parallel_eval(1)
+    path = os.path.join(HERE, "ref_golden_r6.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name, (raw, cfg) in config34_full_cases().items():
+        if only and name not in only:
+            continue
+        t = time.time()
+        r = R.encode_frame(raw, cfg, FULL_FRAMESIZE, trace=True)
+        out[f"cfg/{name}/raw_sha256"] = np.frombuffer(hashlib.sha256(raw.astype(np.int16).tobytes()).digest(), np.uint8)
+        out[f"cfg/{name}/record_sha256"] = np.frombuffer(hashlib.sha256(r["record"]).digest(), np.uint8)
+        out[f"cfg/{name}/record_len"] = np.array([len(r["record"])], np.int64)
+        out[f"cfg/{name}/profile"] = r["profile"]
+        out[f"cfg/{name}/trace_cost"] = r["trace_cost"]
+        out[f"cfg/{name}/wall_seconds_8_threads"] = np.array([time.time() - t])
+        print(name, len(r["record"]), "bytes", round(time.time() - t, 1), "s with 8 evaluation threads", flush=True)
+        np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     R = Checker("ref")
     out = {}
@@ -232,5 +258,7 @@ if __name__ == "__main__":
         main_r4()
     elif "--r5" in sys.argv:
         main_r5()
+    elif "--r6" in sys.argv:
+        main_r6([a for a in sys.argv[1:] if not a.startswith("--")] or None)
     else:
         main()

@@ -152,6 +152,16 @@ def config34_cases():
     return c
 
 
+def config34_full_cases():
+    """BASELINE configs[3] and [4] with the presets' FULL evaluation counts (cmdline.cpp:127-156: --best E = 1000, --veryhigh
+    E = 300), one full-size frame each (round 5): name -> (raw PCM, FrameCfg)."""
+    c = {}
+    c["vh_m8_e300"] = (synth_pcm(20 * FULL_RATE, 1, 3100, FULL_RATE, bits=8), frame_cfg("veryhigh", num_threads=8))
+    c["vh_s16_e300"] = (synth_pcm(20 * FULL_RATE, 2, 3200, FULL_RATE), frame_cfg("veryhigh", num_threads=8))
+    c["best_s16_e1000"] = (synth_pcm(20 * FULL_RATE, 2, 3000, FULL_RATE), frame_cfg("best", num_threads=8))
+    return c
+
+
 def subframe_cases():
     """name -> (pcm [nch,n] int32 raw, blocksamples, min_frame_length): material whose 3-"second"
     blocks alternate between dense and sparse (quantised) PCM, for Codec::Analyse / PushState."""
