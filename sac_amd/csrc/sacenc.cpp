@@ -83,6 +83,7 @@ int main(int argc, char **argv) {
           if (c2 != std::string::npos) cfg.sigma = std::min(std::max(std::atof(v.c_str() + c2 + 1), 0.0), 1.0);
         }
       }
+      else if (a == "--opt-reset") cfg.reset = 1;                                         // cmdline.cpp:193-194 (the batch encoder's default: frames are independent)
       else if (a.rfind("--framelen=", 0) == 0) framelen = std::atoi(a.c_str() + 11);
       else if (a == "--adapt-block=no" || a == "--adapt-block=0") adapt_block = 0;
       else if (a == "--sparse-pcm=no" || a == "--sparse-pcm=0") cfg.sparse_pcm = 0;                         // cmdline.cpp:187-190
