@@ -510,10 +510,14 @@ def main():
         ev = [ctx.eval_stats() for ctx in ctxs]
 
         def kname(kind, cls):
-            if kind == "ols":     # slots 0..2: packed kernels (2-4 items per wave), 3..6: one-wave kernels, 7: 65..96 taps; 11..14: the final pass's panel kernels
+            if kind == "ols":     # names as rocprofv3 prints them (kernels_pred.hip: launch_ols).  Slot = capacity class 16 / 24 / 32 / 40 / 48 / 56 / 64 / 96 taps
+                if os.environ.get("SACAMD_OLS_GRID", "1") != "0" and cls < 8:
+                    # round 5: packed kernel up to 16 taps (and 17..24 in the search), k_ols_grid<NB> for 25..64 taps (17..24 in the final pass), panel kernel above 64
+                    return ("k_ols_pack<16,16>", "k_ols_pack<24,32> (search) + k_ols_grid<3> (final pass)", "k_ols_grid<4>", "k_ols_grid<5>", "k_ols_grid<6>",
+                            "k_ols_grid<7>", "k_ols_grid<8>", "k_ols<256,96>")[cls]
                 if cls >= 8:
                     return f"k_ols<256,{OLS_NMAX[cls - 8]}>"
-                if cls < 3 and os.environ.get("SACAMD_OLS_PACK", "1") != "0":     # names as rocprofv3 prints them (kernels_pred.hip: launch_ols)
+                if cls < 3 and os.environ.get("SACAMD_OLS_PACK", "1") != "0":
                     return ("k_ols_pack<16,16>", "k_ols_pack<24,32>", "k_ols_pack<32,32>")[cls]
                 return f"k_ols<{64 if cls < 7 else 256},{OLS_NMAX[cls]}>"
             return f"k_lms<{cls}>" + (" (canonical order, final pass)" if cls >= 7 else "")

@@ -137,6 +137,11 @@ int sacamd_get_residuals(sacamd_ctx *ctx, int frame, int32_t *error, int32_t *pr
 int sacamd_encode(sacamd_ctx *ctx, const sacamd_cfg *cfg);
 int sacamd_get_encoded(sacamd_ctx *ctx, int frame, int ch, uint8_t *out, int cap, int *len,
                        int *mapped, int *maxbpn);
+/* Both coder variants of a channel after sacamd_encode, as the reference leaves them in FrameCoder::enc_temp1 (variant 0, Normal) and
+ * enc_temp2 (variant 1, Mapped: coded only when the L1 ratio exceeded 1.05, libsac.cpp:253-278); *len = 0 for a variant that was not
+ * coded.  And CalcRemapError's products (libsac.cpp:230-251, with sparse_pcm): s2u_error_map [nch][n] and framestats[].maxbpn_map. */
+int sacamd_get_encoded_variant(sacamd_ctx *ctx, int frame, int ch, int variant, uint8_t *out, int cap, int *len, int *maxbpn);
+int sacamd_get_residuals_map(sacamd_ctx *ctx, int frame, int32_t *s2u_map, int *maxbpn_map);
 
 /* ---- (6) whole batch: Predict + Encode + WriteEncoded -------------------------------------
  * Replaces: the per-frame sequence FrameCoder::Predict(); Encode(); WriteEncoded()

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
     "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
     "sacamd_decode_frames", "sacamd_comm_unique_id", "sacamd_comm_create", "sacamd_comm_destroy", "sacamd_comm_last_error",
-    "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_debug_libm", "sacamd_predictor_streams",
+    "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_debug_libm", "sacamd_predictor_streams", "sacamd_get_encoded_variant", "sacamd_get_residuals_map",
 ]
 
 
@@ -357,6 +357,21 @@ class Context:
         ln, mp, mb = c_int(0), c_int(0), c_int(0)
         self._chk(self.lib.sacamd_get_encoded(self.h, frame, ch, _vp(out), out.size, byref(ln), byref(mp), byref(mb)))
         return out[: ln.value].tobytes(), mp.value, mb.value
+
+    def encoded_variant(self, frame: int, ch: int, variant: int):
+        """(bytes, maxbpn) of the Normal (0) / Mapped (1) coder stream of a channel, b"" if that variant was not coded (enc_temp1 / enc_temp2)"""
+        n = int(self.numsamples[frame])
+        out = np.zeros(n * 4 + 40000, np.uint8)
+        ln, mb = c_int(0), c_int(0)
+        self._chk(self.lib.sacamd_get_encoded_variant(self.h, frame, ch, variant, _vp(out), out.size, byref(ln), byref(mb)))
+        return out[: ln.value].tobytes(), mb.value
+
+    def residuals_map(self, frame: int):
+        """(s2u_error_map [nch, n], maxbpn_map [nch]) after encode() with sparse_pcm (CalcRemapError)"""
+        n = int(self.numsamples[frame])
+        m = np.zeros((self.nch, n), np.int32); mb = np.zeros(self.nch, np.int32)
+        self._chk(self.lib.sacamd_get_residuals_map(self.h, frame, _vp(m), _vp(mb)))
+        return m, mb
 
     def encode_frames(self, cfg: Cfg, profiles=None):
         """Predict + Encode + WriteEncoded for every staged frame -> (list of records, profiles)."""

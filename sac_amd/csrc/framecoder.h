@@ -159,6 +159,23 @@ class FrameCoder {
       encoded[ch].assign(tmp.data(), (size_t)len);
       framestats[ch].enc_mapped = mapped != 0; framestats[ch].blocksize = len;
       (mapped ? framestats[ch].maxbpn_map : framestats[ch].maxbpn) = mb;
+      // what EncodeMonoFrame leaves beside `encoded` (libsac.cpp:253-278): enc_temp1 = the Normal stream, enc_temp2 = the Mapped one (if it was tried)
+      for (int variant = 0; variant < 2; variant++) {
+        BufIO &dst = variant ? enc_temp2[ch] : enc_temp1[ch];
+        int vl = 0, vmb = 0;
+        chk(sacamd_get_encoded_variant(ctx_, 0, ch, variant, nullptr, 0, &vl, &vmb));
+        dst.Reset();
+        if (vl > 0) { tmp.resize((size_t)vl + 1); chk(sacamd_get_encoded_variant(ctx_, 0, ch, variant, tmp.data(), vl, &vl, &vmb)); dst.assign(tmp.data(), (size_t)vl); }
+      }
+    }
+    if (c.sparse_pcm) {     // CalcRemapError's products (libsac.cpp:230-251): s2u_error_map, framestats[].maxbpn_map
+      std::vector<int32_t> m((size_t)numchannels_ * numsamples_);
+      int mbm[2] = {0, 0};
+      chk(sacamd_get_residuals_map(ctx_, 0, m.data(), mbm));
+      for (int ch = 0; ch < numchannels_; ch++) {
+        std::memcpy(s2u_error_map[ch].data(), &m[(size_t)ch * numsamples_], sizeof(int32_t) * (size_t)numsamples_);
+        framestats[ch].maxbpn_map = mbm[ch];
+      }
     }
   }
 
@@ -219,7 +236,7 @@ class FrameCoder {
   }
 
   std::vector<std::vector<int32_t>> samples, error, s2u_error, s2u_error_map, pred;   // public buffers, libsac.h:54
-  std::vector<BufIO> encoded, enc_temp1, enc_temp2;                                    // libsac.h:55 (the temporaries stay empty: both coder variants run on the device)
+  std::vector<BufIO> encoded, enc_temp1, enc_temp2;                                    // libsac.h:55 (enc_temp1 / enc_temp2: the Normal / Mapped stream after Encode(), as in the reference)
   std::vector<FrameStats> framestats;
   SacProfile base_profile;                                                             // 58 coefficients; .coefs[i].vdef is what a frame record stores
 

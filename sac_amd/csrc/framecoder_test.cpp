@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include "framecoder.h"
@@ -109,6 +110,13 @@ int main(int argc, char **argv) {
       coder.SetNumSamples(n);
       coder.Predict();
       coder.Encode();
+      // the public buffers EncodeMonoFrame leaves behind (libsac.cpp:253-278): `encoded` is enc_temp2 when the Mapped variant won, else enc_temp1
+      for (int ch = 0; ch < nch; ch++) {
+        sacamd::BufIO &win = coder.framestats[ch].enc_mapped ? coder.enc_temp2[ch] : coder.enc_temp1[ch];
+        if (win.GetBufPos() != coder.encoded[ch].GetBufPos() ||
+            std::memcmp(win.GetBuf().data(), coder.encoded[ch].GetBuf().data(), win.GetBufPos()) != 0) { std::fprintf(stderr, "enc_temp buffers do not hold the chosen stream\n"); return 3; }
+        if (coder.framestats[ch].enc_mapped && coder.enc_temp1[ch].GetBufPos() <= coder.enc_temp2[ch].GetBufPos()) { std::fprintf(stderr, "Mapped chosen although not smaller\n"); return 3; }
+      }
       coder.WriteEncoded(out);
     }
   } catch (const std::exception &e) { std::fprintf(stderr, "framecoder_test: %s\n", e.what()); return 1; }

@@ -140,7 +140,9 @@ struct sacamd_ctx {
   int dec_side = 0;               // decoder: pooled side stream found to run beside the main stream
   DevBuf<long long> d_out3;
   bool coder_tables = false;
-  struct EncOut { std::vector<unsigned char> bytes; int mapped = 0, maxbpn = 0; };
+  // bytes: the chosen variant (libsac.cpp:253-278); other: the variant that lost, when both were coded (what the reference leaves in
+  // enc_temp1 / enc_temp2); maxbpn_map: planes of the remapped residual (valid with sparse_pcm, CalcRemapError :230-251)
+  struct EncOut { std::vector<unsigned char> bytes, other; int mapped = 0, maxbpn = 0, maxbpn_other = 0, both = 0, maxbpn_map = 0; };
   std::vector<EncOut> enc;   // [frame*nch+ch]
   // per-channel search costs already computed for the staged batch: key = (frame, channels, window,
   // every predictor parameter of the slot) as raw bytes -> cost of that channel's residual

@@ -159,6 +159,7 @@ def config34_full_cases():
     c["vh_m8_e300"] = (synth_pcm(20 * FULL_RATE, 1, 3100, FULL_RATE, bits=8), frame_cfg("veryhigh", num_threads=8))
     c["vh_s16_e300"] = (synth_pcm(20 * FULL_RATE, 2, 3200, FULL_RATE), frame_cfg("veryhigh", num_threads=8))
     c["best_s16_e1000"] = (synth_pcm(20 * FULL_RATE, 2, 3000, FULL_RATE), frame_cfg("best", num_threads=8))
+    c["best_s16_e100"] = (synth_pcm(20 * FULL_RATE, 2, 3000, FULL_RATE), frame_cfg("best", num_threads=8, maxnfunc=100))    # a tenth of the preset: what a GPU call can time
     return c
 
 

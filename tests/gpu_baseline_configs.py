@@ -67,7 +67,7 @@ def main():
     if a.full:
         from golden_cases import config34_full_cases
         g6 = np.load(os.path.join(ROOT, "tests", "golden", "ref_golden_r6.npz"))
-        spec = {"vh_m8_e300": (a.frames_vh, 1, 8, 3100), "vh_s16_e300": (a.frames_vh, 2, 16, 3200), "best_s16_e1000": (a.frames_best, 2, 16, 3000)}
+        spec = {"vh_m8_e300": (a.frames_vh, 1, 8, 3100), "vh_s16_e300": (a.frames_vh, 2, 16, 3200), "best_s16_e1000": (a.frames_best, 2, 16, 3000), "best_s16_e100": (a.frames_best, 2, 16, 3000)}
         for name in a.full.split(","):
             nf, nch, bits, seed0 = spec[name]
             print(json.dumps(run(name, nf, nch, bits, seed0, g6, cases=config34_full_cases())), flush=True)

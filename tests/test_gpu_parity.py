@@ -241,6 +241,40 @@ def test_final_pass_layout_choice_respects_the_lds(api, orc):
     ctx.close()
 
 
+def test_both_coder_variants_and_remap_products_are_readable(api, orc, golden):
+    """What EncodeMonoFrame leaves in the FrameCoder's public buffers beside `encoded` (libsac.cpp:230-278, libsac.h:54-56): the Normal and
+    the Mapped stream (enc_temp1 / enc_temp2), s2u_error_map and framestats[].maxbpn_map -- readable through the C ABI
+    (sacamd_get_encoded_variant, sacamd_get_residuals_map; sacamd::FrameCoder::Encode fills the wrapper's members from them).  Sparse
+    16-bit frame of the golden set (the Mapped variant wins) and a dense one (Mapped, if tried at all, loses)."""
+    raw = golden["frame/sparse16_normal/raw"]
+    ctx = api.Context(raw.shape[0], FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    cfg = api.make_cfg("normal")
+    ctx.analyse(cfg); ctx.predict_final(cfg, golden["profile"][:, 2].astype(np.float32)[None, :]); ctx.encode(cfg)
+    chosen, mapped, mb = ctx.encoded(0, 0)
+    normal, mbn = ctx.encoded_variant(0, 0, 0)
+    mapd, mbm = ctx.encoded_variant(0, 0, 1)
+    assert mapped == 1 and chosen == mapd and mb == mbm and len(normal) > len(mapd) > 0
+    assert mapd == golden["frame/sparse16_normal/record"].tobytes()[4 + 232 + 18:]
+    smp, stats = center_frame(raw)
+    err, pred = orc.predict_frame(smp, stats, golden["profile"][:, 2].copy(), 0, raw.shape[1], 0)
+    _, s2m, mbm_want, _, _ = orc.remap(raw[0], pred[0], err[0])
+    u = np.where(err[0] < 0, -2 * err[0].astype(np.int64), np.where(err[0] > 0, 2 * err[0].astype(np.int64) - 1, 0)).astype(np.int32)
+    assert normal == orc.bitplane_encode(u, mbn)
+    m, mbv = ctx.residuals_map(0)
+    assert np.array_equal(m[0], np.asarray(s2m, np.int32)) and int(mbv[0]) == int(mbm_want)
+    ctx.close()
+    raw = golden["frame/s16_normal/raw"]
+    ctx = api.Context(raw.shape[0], FRAMESIZE, 1)
+    ctx.upload_i32([raw], FRAMESIZE)
+    ctx.analyse(cfg); ctx.predict_final(cfg, golden["profile"][:, 2].astype(np.float32)[None, :]); ctx.encode(cfg)
+    for ch in range(raw.shape[0]):
+        chosen, mapped, _ = ctx.encoded(0, ch)
+        lost, _ = ctx.encoded_variant(0, ch, 1)          # coded only when the L1 ratio exceeded 1.05; here it did not win (libsac.cpp:265-275)
+        assert mapped == 0 and ctx.encoded_variant(0, ch, 0)[0] == chosen and (lost == b"" or len(lost) >= len(chosen))
+    ctx.close()
+
+
 def test_full_size_roundtrip_property(api, orc):
     """BASELINE-size property: a 44.1 kHz stereo frame encoded on the GPU (--normal) decodes to the
     input with the CPU decoder (encode -> decode round trip), and bps is sane."""

@@ -26,7 +26,7 @@ def totals(d):
 
 fetch, nd = totals(fetch_dir)
 write, _ = totals(write_dir)
-stage_bytes = {"k_ols": 16, "k_lms": 20}
+stage_bytes = {"k_ols": 16, "k_ols_grid": 16, "k_ols_pack": 16, "k_lms": 20}
 res = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- bench.py {line['config']['workload']}; "
                  "counters in KB (TCC_EA0 based, Infinity-Cache hits included; 4- and 8-byte per-lane accesses: uncalibrated, see MI355X_MICROARCH.md HBM section)",
        "kernels": {}}
