@@ -264,7 +264,8 @@ int sacamd_class_times(sacamd_ctx *ctx, double *out128, int cap, int reset);
 int sacamd_progress(const sacamd_ctx *ctx, int *phase, int *generation);
 
 /* debug: on!=0 enables per-section cycle counters in the predictor kernels (slows them slightly);
- * out16 (nullable, 16 entries) receives the counters of the last launch.  One-wave OLS kernel:
+ * out16 (nullable, 16 entries) receives the counters of the last launch (k_ols_grid and the round-1..4 OLS kernels; the packed kernels of
+ * the <= 16-tap class -- and of 17..24 taps in the search -- carry no counters and leave zeros).  One-wave OLS kernel:
  * [0] regressor+predict+pow [1] covariance update [2] LDL^T factor [3] forward solve [4] backward solve [5] tail.
  * Cascade kernel (wave 0): [8] tap sweep [9] wave reduction [10] barrier [11] predict+targets
  * [12] stage gains / experts / P x [13] RLS scalars + blend [14] P update [15] closing barrier */
