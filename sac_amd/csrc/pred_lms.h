@@ -42,9 +42,12 @@ struct LmsClass {
   SA_HD static constexpr int first(int s) { return s == 0 ? 0 : s == 1 ? C0 : s == 2 ? C0 + C1 : C0 + C1 + C2; }
 };
 constexpr int kRlsMax = 10;
-// taps per lane whose history loads are issued together in the sweep: four where the tap state leaves
-// registers to spare, two in the large classes (which already overflow the 256-VGPR budget)
-template <class C> constexpr int lms_group() { return C::total > 16 ? 2 : 4; }
+#ifndef SACAMD_EXP_LMS_AHEAD
+#define SACAMD_EXP_LMS_AHEAD 3
+#endif
+// search sweep: slots whose history loads are in flight ahead of the arithmetic (4 registers per slot); the 30-slot layouts
+// already fill the 256-VGPR budget with their tap state
+template <class C> constexpr int lms_ahead() { return C::total > 22 ? 2 : SACAMD_EXP_LMS_AHEAD; }
 
 template <int N> struct DArr { double v[N]; };
 
@@ -141,10 +144,12 @@ struct LmsLds {
   int *sv;
   // ringcap[s] >= vn[s] + 1 of every work-item of the launch (<= C::slots(s) * NL + 1): the LDS
   // footprint follows the taps actually in use, not the register-capacity class
+  // search layouts (CANON 0, round 6): the sweep visits every slot of the layout, so every ring has the layout's capacity
+  SA_HD static constexpr int cap_of(int s, int c) { return CANON ? c : C::slots(s) * NL + 1; }
   SA_HD static size_t bytes(const int *ringcap) {
     size_t d = 0;
     #pragma unroll
-    for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringlen(ringcap[s])) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
+    for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringlen(cap_of(s, ringcap[s]))) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
     if (CANON) d += 64 + 32 + 64 + 32;
     if (CANON == 3) d += (size_t)(NL / 2) * C::c0;     // mutab of the dot lanes, lane-major per wave
     d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
@@ -163,7 +168,7 @@ struct LmsLds {
       csum = d; d += 64; psum = d; d += 32; tailw = d; d += 64; tailpw = d; d += 32;
     }
     #pragma unroll
-    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ridx(ringlen(ringcap[s])) + 1; }
+    for (int s = 0; s < 4; s++) { ring[s] = d; d += (size_t)ridx(ringlen(cap_of(s, ringcap[s]))) + 1; }
     #pragma unroll
     for (int s = 0; s < 4; s++) { mt[s] = pt[s] = nullptr; if (CANON == 1) { mt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; pt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; } }
     if (CANON == 3) { mt[0] = d; d += (size_t)(NL / 2) * C::c0; }
@@ -225,6 +230,49 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
   return init;
 }
 
+// ---- search sweep (CANON 0), one stage of one lane: all SL tap slots of the layout, straight-line ----
+// Round 6.  The sweep used to be one uniform branch per slot (slots beyond the stage length were skipped) with the slot's ring load,
+// its `s_waitcnt lgkmcnt(0)` and its seven dependent fp64 operations inside: every slot paid a full LDS round trip (~300 cycles per
+// 256-tap slot against ~40 of issue), and the branch conditions of 22 slots overflowed the scalar registers.  Now a stage's sweep has
+// no branch at all: every slot of the layout is swept -- a tap beyond the stage length is arithmetically neutral, its mutab / powtab
+// entries are zero and its weight stays +0: fma(0, ., w) = w, fma(x, 0, d) = d, fma(0, ., sp) = sp -- and the history loads of slot
+// j + AHEAD are in flight under slot j's arithmetic.  For that every tap of the layout must read a finite value, so the rings of
+// the search layouts have the LAYOUT's capacity (cap = SL NL + 1), not the item's (they are zero-filled at the start; LDS per
+// workgroup is the layout's maximum, which the big launches of a batch search reached anyway).
+// Addresses: slot j of lane l reads ring[(ps + l + NL j) mod cap] and its successor (ring[cap] mirrors ring[0]).  Two bases per lane
+// and stage -- a0 = ring + ps + l and a1 = a0 - cap -- and one compare per slot (NL j >= cap - ps - l) select the wrapped one; the
+// slot's offset NL j is a constant.  Operation order per tap and summation order over the slots are those of the rounds 1-5 sweep,
+// and the neutral slots add exact zeros: results are bit-identical to it.
+template <int NL, int F, int SL, int AHEAD, class T>
+SA_HD void lms_sweep_stage(T &Wl, const T &MTl, const T &PTl, const double *ring, int ps, int l, double wg, double &d_out, double &sp_out) {
+  constexpr int G = AHEAD < SL ? AHEAD : SL;
+  constexpr int cp = SL * NL + 1;
+  const int u = ps + l;
+  const double *a0 = ring + u, *a1 = a0 - cp;
+  const int thr = cp - u;                                  // slot j wraps iff NL j >= thr
+  double bn[G], bo[G];
+  auto load = [&](auto JC) {
+    constexpr int j = decltype(JC)::value;
+    const double *a = (j * NL >= thr) ? a1 : a0;
+    bn[j % G] = a[j * NL]; bo[j % G] = a[j * NL + 1];
+  };
+  static_for<0, G>(load);
+  double d = 0.0, sp = 0.0;
+  static_for<0, SL>([&](auto JC) {
+    constexpr int j = decltype(JC)::value;
+    const double xn = bn[j % G], xo = bo[j % G];
+    if constexpr (j + G < SL) load(std::integral_constant<int, j + G>{});
+    double w = fma(MTl.v[F + j], wg * xo, Wl.v[F + j]);
+    w = clampd(w, -10.0, 10.0);
+    Wl.v[F + j] = w;
+    d = fma(xn, w, d);
+    sp = fma(PTl.v[F + j], xn * xn, sp);
+    SA_PIN_F64(d); SA_PIN_F64(sp);     // the slot's arithmetic stays in front of the fence ...
+    SA_SCHED_FENCE();                  // ... across which the scheduler moves nothing (else it hoists every load of the stage to its top: 4 registers per slot, spills)
+  });
+  d_out = d; sp_out = sp;
+}
+
 template <class E, class C, int CANON = 0, int ROUNDS = 1>
 SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const double *tab,
                      const int *self, int n, const double *pin_g, double *pout_g, char *lds_base, const int *ringcap,
@@ -262,7 +310,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
 
   int ns[4], cap[4], pos[4];
   #pragma unroll
-  for (int s = 0; s < 4; s++) { ns[s] = p.vn[s]; cap[s] = ns[s] + 1; pos[s] = 0; if (LM && cap[s] < EXT3) cap[s] = EXT3; }
+  for (int s = 0; s < 4; s++) { ns[s] = p.vn[s]; cap[s] = CANON ? ns[s] + 1 : C::slots(s) * NL + 1; pos[s] = 0; if (LM && cap[s] < EXT3) cap[s] = EXT3; }
   if constexpr (LM) { canon3_pack(ns, J3, D3, 0, -1, nullptr, &G3d); canon3_pack(ns, J3, D3, 1, -1, nullptr, &G3p); }
   const int m = p.lm_n;
 
@@ -366,6 +414,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   }
   // ring s starts ro1 + .. + ro_s doubles after ring[0]
   const int ro1 = (int)(L.ring[1] - L.ring[0]), ro2 = (int)(L.ring[2] - L.ring[1]), ro3 = (int)(L.ring[3] - L.ring[2]);
+  const int rofs[4] = {0, ro1, ro1 + ro2, ro1 + ro2 + ro3};                                                    // search sweep: ring s = ring[0] + rofs[s] (one LDS base)
   // uniform mixer state (wave 0)
   double smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0, denom = 0.0, inv_alpha = 0.0, phi = 0.0;   // wave 3 / wave 2 uniform state
   bool have_prev = false;
@@ -388,46 +437,12 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       // ---- A: fused sweep (update of previous step, predict of this step)
       if constexpr (!CANON) {
       ex.par([&](int l) {
-        #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int f = C::first(s);
-          const double wg = L.bc[s];
-          double d = 0.0, sp = 0.0;
-          const double *ring = L.ring[s];
-          // Slots are processed in groups of kLmsGroup with all ring loads of a group issued before its
-          // arithmetic (one LDS round trip per group, not per tap).  Within an active group a lane
-          // whose tap lies beyond the stage length reads the last tap's history instead: its mutab /
-          // powtab entries are zero and its weight stays +0, so fma(0, ., w), fma(x, 0, d) and
-          // fma(0, ., sp) leave w, d and sp exactly as they were.
-          const int last = ns[s] - 1, cp = cap[s], ps = pos[s];
-          constexpr int kLmsGroup = lms_group<C>();
-#pragma unroll
-          for (int j0 = 0; j0 < C::slots(s); j0 += kLmsGroup) {
-            if (j0 * NL < ns[s]) {
-              double xo[kLmsGroup], xn[kLmsGroup];
-#pragma unroll
-              for (int g = 0; g < kLmsGroup; g++) {
-                if (j0 + g < C::slots(s)) {
-                  int tap = (j0 + g) * NL + l; tap = tap < last ? tap : last;
-                  int in = ps + tap; if (in >= cp) in -= cp;
-                  xn[g] = ring[in]; xo[g] = ring[in + 1];
-                }
-              }
-#pragma unroll
-              for (int g = 0; g < kLmsGroup; g++) {
-                if (j0 + g < C::slots(s) && (j0 + g) * NL < ns[s]) {     // (uniform) slots beyond the stage length
-                  const int j = j0 + g;
-                  double w = fma(MT[l].v[f + j], wg * xo[g], W[l].v[f + j]);
-                  w = clampd(w, -10.0, 10.0);
-                  W[l].v[f + j] = w;
-                  d = fma(xn[g], w, d);
-                  sp = fma(PT[l].v[f + j], xn[g] * xn[g], sp);
-                }
-              }
-            }
-          }
+        static_for<0, 4>([&](auto SC) {
+          constexpr int s = decltype(SC)::value;
+          double d, sp;
+          lms_sweep_stage<NL, C::first(s), C::slots(s), lms_ahead<C>()>(W[l], MT[l], PT[l], L.ring[0] + rofs[s], pos[s], l, L.bc[s], d, sp);
           acc[l].v[s] = d; acc[l].v[4 + s] = sp;
-        }
+        });
       });
       SA_TICK(0);
       ex.wave_sum8x(acc);

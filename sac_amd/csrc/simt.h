@@ -27,7 +27,9 @@
 #define SA_OPAQUE_INT(x) asm volatile("" : "+v"(x))
 #define SA_OPAQUE_SINT(x) asm volatile("" : "+s"(x))      // same for a wave-uniform value held in an SGPR
 #define SA_PIN_F64(x) asm volatile("" : "+v"(x))          // the computation of x stays in this basic block (not sunk / merged across branches)
+#define SA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0) // the instruction scheduler moves nothing across this point (software-pipelined straight-line code)
 #else
+#define SA_SCHED_FENCE() ((void)0)
 #define SA_PIN_F64(x) ((void)0)
 #define SA_OPAQUE_INT(x) ((void)0)
 #define SA_OPAQUE_SINT(x) ((void)0)

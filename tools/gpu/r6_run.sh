@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 6 GPU calls, one parameterised script: tools/gpu/r6_run.sh <step> (run on the GPU box through gpurun)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06; mkdir -p $O
+TP='1280,256,32,4;1500,2500,900,400;3300,1200,700,250;3900,1900,900,400'
+case "$1" in
+  sweep1)   # pipelined search sweep: parity subset, section cycles, saturated throughput (base + prefetch depth 4)
+    timeout 900 python -m pytest tests -q -m gpu -x -k "random_profiles or predictor_stages or evaluate_costs or headline or kept_ols" > $O/gputests_01_sweep_subset.log 2>&1
+    tail -3 $O/gputests_01_sweep_subset.log
+    timeout 300 python tests/gpu_latency.py > $O/latency_sections_sweep1.txt 2>&1; grep -B1 "k=4" $O/latency_sections_sweep1.txt | cut -c1-150
+    timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_sweep1.txt 2>&1; grep "16 taps" $O/throughput_lms_sweep1.txt | cut -c1-160
+    SACAMD_LIB_PATH=$GRAFT_REPO_ROOT/sac_amd/libsac_amd_ahead4.so timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_sweep1_ahead4.txt 2>&1; grep "16 taps" $O/throughput_lms_sweep1_ahead4.txt | cut -c1-160
+    ;;
+  bench768)
+    timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_$2.json 2> $O/bench_768_$2.err
+    tail -c 1500 $O/bench_768_$2.json
+    ;;
+esac
