@@ -61,7 +61,8 @@ static int predictor_main(int argc, char **argv) {
     sacamd::FrameCoder::SetParam(param, profile, optimize);
     Range r0{framestats[0].minval, framestats[0].maxval};
     Range r1 = r0; if (numchannels_ == 2) r1 = {framestats[1].minval, framestats[1].maxval};
-    Predictor pr(r0, r1, param, numsamples);
+    if (numchannels_ == 1) Predictor::frame_length_hint(numsamples);   // mono never calls fillbuf_ch1, which is where the length arrives in stereo
+    Predictor pr(r0, r1, param);                                       // libsac.cpp:102, unchanged
     auto eprocess = [&](int ch_p, int ch, int32_t val, int idx) {
       double pd = pr.predict(ch_p);
       const double rd = std::round(pd);

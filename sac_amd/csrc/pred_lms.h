@@ -243,34 +243,43 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
 // and stage -- a0 = ring + ps + l and a1 = a0 - cap -- and one compare per slot (NL j >= cap - ps - l) select the wrapped one; the
 // slot's offset NL j is a constant.  Operation order per tap and summation order over the slots are those of the rounds 1-5 sweep,
 // and the neutral slots add exact zeros: results are bit-identical to it.
-template <int NL, int F, int SL, int AHEAD, class T>
-SA_HD void lms_sweep_stage(T &Wl, const T &MTl, const T &PTl, const double *ring, int ps, int l, double wg, double &d_out, double &sp_out) {
-  constexpr int G = AHEAD < SL ? AHEAD : SL;
-  constexpr int cp = SL * NL + 1;
-  const int u = ps + l;
-  const double *a0 = ring + u, *a1 = a0 - cp;
-  const int thr = cp - u;                                  // slot j wraps iff NL j >= thr
+// The four stages' slots form ONE pipeline (flat slot q = C::first(s) + j): the loads of the next stage's first slots are in flight
+// under the last slots of the stage before, so a sample exposes one LDS round trip, not four.
+template <class C> SA_HD constexpr int lms_flat_stage(int q) { return q < C::first(1) ? 0 : (q < C::first(2) ? 1 : (q < C::first(3) ? 2 : 3)); }
+template <int NL, class C, int AHEAD, class T, class A8>
+SA_HD void lms_sweep(T &Wl, const T &MTl, const T &PTl, A8 &accl, const double *ring0, const int *rofs, const int *pos, const double *bc, int l) {
+  constexpr int TOT = C::total, G = AHEAD < TOT ? AHEAD : TOT;
   double bn[G], bo[G];
-  auto load = [&](auto JC) {
-    constexpr int j = decltype(JC)::value;
-    const double *a = (j * NL >= thr) ? a1 : a0;
-    bn[j % G] = a[j * NL]; bo[j % G] = a[j * NL + 1];
+  const double *a0[4], *a1[4];
+  int thr[4];
+  double wg[4];
+  auto load = [&](auto QC) {
+    constexpr int q = decltype(QC)::value, s = lms_flat_stage<C>(q), j = q - C::first(s);
+    constexpr int cp = C::slots(s) * NL + 1;
+    if constexpr (j == 0) {                               // first slot of a stage: its bases and its gain
+      const int u = pos[s] + l;
+      a0[s] = ring0 + rofs[s] + u; a1[s] = a0[s] - cp; thr[s] = cp - u;      // slot j wraps iff NL j >= thr
+      wg[s] = bc[s];
+    }
+    const double *a = (j * NL >= thr[s]) ? a1[s] : a0[s];
+    bn[q % G] = a[j * NL]; bo[q % G] = a[j * NL + 1];
   };
   static_for<0, G>(load);
   double d = 0.0, sp = 0.0;
-  static_for<0, SL>([&](auto JC) {
-    constexpr int j = decltype(JC)::value;
-    const double xn = bn[j % G], xo = bo[j % G];
-    if constexpr (j + G < SL) load(std::integral_constant<int, j + G>{});
-    double w = fma(MTl.v[F + j], wg * xo, Wl.v[F + j]);
+  static_for<0, TOT>([&](auto QC) {
+    constexpr int q = decltype(QC)::value, s = lms_flat_stage<C>(q), j = q - C::first(s);
+    if constexpr (j == 0) { d = 0.0; sp = 0.0; }
+    const double xn = bn[q % G], xo = bo[q % G];
+    if constexpr (q + G < TOT) load(std::integral_constant<int, q + G>{});
+    double w = fma(MTl.v[q], wg[s] * xo, Wl.v[q]);
     w = clampd(w, -10.0, 10.0);
-    Wl.v[F + j] = w;
+    Wl.v[q] = w;
     d = fma(xn, w, d);
-    sp = fma(PTl.v[F + j], xn * xn, sp);
+    sp = fma(PTl.v[q], xn * xn, sp);
     SA_PIN_F64(d); SA_PIN_F64(sp);     // the slot's arithmetic stays in front of the fence ...
-    SA_SCHED_FENCE();                  // ... across which the scheduler moves nothing (else it hoists every load of the stage to its top: 4 registers per slot, spills)
+    SA_SCHED_FENCE();                  // ... across which the scheduler moves nothing (else it hoists every load of the sweep to its top: 4 registers per slot, spills)
+    if constexpr (j == C::slots(s) - 1) { accl.v[s] = d; accl.v[4 + s] = sp; }
   });
-  d_out = d; sp_out = sp;
 }
 
 template <class E, class C, int CANON = 0, int ROUNDS = 1>
@@ -436,14 +445,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       const int par = tt & 1;
       // ---- A: fused sweep (update of previous step, predict of this step)
       if constexpr (!CANON) {
-      ex.par([&](int l) {
-        static_for<0, 4>([&](auto SC) {
-          constexpr int s = decltype(SC)::value;
-          double d, sp;
-          lms_sweep_stage<NL, C::first(s), C::slots(s), lms_ahead<C>()>(W[l], MT[l], PT[l], L.ring[0] + rofs[s], pos[s], l, L.bc[s], d, sp);
-          acc[l].v[s] = d; acc[l].v[4 + s] = sp;
-        });
-      });
+      ex.par([&](int l) { lms_sweep<NL, C, lms_ahead<C>()>(W[l], MT[l], PT[l], acc[l], L.ring[0], rofs, pos, L.bc, l); });
       SA_TICK(0);
       ex.wave_sum8x(acc);
       SA_TICK(1);

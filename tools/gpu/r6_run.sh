@@ -11,6 +11,14 @@ case "$1" in
     timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_sweep1.txt 2>&1; grep "16 taps" $O/throughput_lms_sweep1.txt | cut -c1-160
     SACAMD_LIB_PATH=$GRAFT_REPO_ROOT/sac_amd/libsac_amd_ahead4.so timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_sweep1_ahead4.txt 2>&1; grep "16 taps" $O/throughput_lms_sweep1_ahead4.txt | cut -c1-160
     ;;
+  sweep2)   # the four stages as one pipeline; Predictor's three-argument constructor; one 768-frame step
+    timeout 600 python -m pytest tests -q -m gpu -x -k "predictor_class or predictor_surface or predictor_stages or evaluate_costs" > $O/gputests_02_sweep2_subset.log 2>&1
+    tail -3 $O/gputests_02_sweep2_subset.log
+    timeout 300 python tests/gpu_latency.py > $O/latency_sections_sweep2.txt 2>&1; grep -B1 "k=4" $O/latency_sections_sweep2.txt | cut -c1-150 | head -12
+    timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_sweep2.txt 2>&1; grep "16 taps" $O/throughput_lms_sweep2.txt | cut -c1-160
+    timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_sweep2.json 2> $O/bench_768_sweep2.err
+    tail -c 2500 $O/bench_768_sweep2.json
+    ;;
   bench768)
     timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_$2.json 2> $O/bench_768_$2.err
     tail -c 1500 $O/bench_768_$2.json
