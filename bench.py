@@ -131,6 +131,19 @@ def shard_frames(total_frames, rank, world, cost=None):
     return [f for f in range(total_frames) if owner[f] == rank]
 
 
+def restore_frame_order(rank_major, cost, world, total_frames):
+    """Records as the torch.distributed gather delivers them on rank 0 (rank-major: all of rank 0's frames, then rank 1's, ...,
+    each rank's in ascending frame id as shard_frames hands them out) -> frame order, with the ownership every rank computed
+    from the same cost list (sacamd_assign_frames).  --scaling strong with --gather torch."""
+    import sac_amd.api as api
+    owner = api.assign_frames(cost, world)
+    order = [f for r in range(world) for f in range(total_frames) if owner[f] == r]
+    if len(order) != len(rank_major):
+        raise RuntimeError(f"gather returned {len(rank_major)} records for {len(order)} owned frames")
+    got = dict(zip(order, rank_major))
+    return [got[f] for f in range(total_frames)]
+
+
 def gather_records(recs, rank, world, device):
     """Variable-length gather of frame records to rank 0 (RCCL on GPUs, gloo in the CPU tests):
     all_gather of the per-frame lengths, then one gather of the padded payloads."""
@@ -375,10 +388,7 @@ def main():
         out = gather_records(recs, rank, world, device)       # rank-major order
         if out is None or args.scaling != "strong":
             return out
-        owner = api.assign_frames(cost, world)
-        order = [f for r in range(world) for f in range(total_frames) if owner[f] == r]
-        got = dict(zip(order, out))
-        return [got[f] for f in range(total_frames)]
+        return restore_frame_order(out, cost, world, total_frames)
 
     t_h2d = time.perf_counter()
     d_pcm = torch.from_numpy(il).to(device)            # interleaved L/R int16, resident in HBM

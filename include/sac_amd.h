@@ -16,20 +16,22 @@
  * gfx950 device/kernel image is available, sacamd_ctx_create fails with SACAMD_ERR_NOGPU.
  *
  * Hardware queues: HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read at the process's first HIP call.  The
- * library sets it to 24 when it is loaded unless the environment already has it; sacamd_ctx_create refuses (SACAMD_ERR_STATE, message on
- * stderr) a value below 16 unless SACAMD_ALLOW_FEW_QUEUES=1.  A host that has initialised HIP before loading the library exports it itself.
+ * library sets it to 24 when it is loaded unless the environment already has it.  sacamd_ctx_create warns once on stderr (round 6; it
+ * used to refuse) when the caller's own value is below 16, and when the library had to set the variable although a HIP-using module
+ * (torch) was loaded first -- HIP may have read the default already.  A host that initialises HIP before loading the library exports it itself.
  *
  * Environment switches (read once per process; every one is an A/B or diagnostic aid, the defaults are the product):
  *   SACAMD_TRACE=1             every predictor launch with its duration and start offset on stderr; at context destruction the search
  *                              cascade's work by tap count.  SACAMD_DUMP_VN=file (with TRACE) writes the stage lengths of every search item.
- *   SACAMD_OLS_GRID=0          33..64-tap OLS items on the round-4 kernels (one-wave row layout in the search, four-wave panel kernel in
- *                              the final pass: SACAMD_OLS_FINAL_PANEL=0 keeps the one-wave kernel there too) instead of k_ols_grid.
+ *   SACAMD_OLS_GRID=0          33..64-tap OLS items on the round-4 KERNELS (one-wave row layout in the search, four-wave panel kernel in
+ *                              the final pass: SACAMD_OLS_FINAL_PANEL=0 keeps the one-wave kernel there too) instead of k_ols_grid.  Not the
+ *                              round-4 SCHEDULE: the panel slot budget and the host-side head start of run_predict went with round 5, so every
+ *                              33..64-tap class of the final pass starts on the panel kernel at once (the round-3 set-up) -- a kernel A/B only.
  *   SACAMD_OLS_GRID_SHORT=0    17..32-tap items on the packed kernels everywhere.   SACAMD_OLS_PACK=0: one item per wave up to 32 taps.
  *   SACAMD_FAST_OLS=n          search: OLS classes [0, n) form the cascade's first launch group (default 3).
  *   SACAMD_FINAL_GROUPS=1      final pass: one cascade launch group per OLS class (measured as a loss).
  *   SACAMD_CODER_SERIAL=1      parity tap: the coder's decision chain on one lane (the body the CPU emulation runs).
  *   SACAMD_DEC_SINGLE=1        decoder: every frame group as one cooperative launch (the fallback form).  SACAMD_DEC_ZERO=0 skips zeroing its planes.
- *   SACAMD_ALLOW_FEW_QUEUES=1  see above.
  * (Rounds 2-4 had more: tail priorities, chase mode, pipelining, the panel-kernel slot budget and head start -- all measured, documented in
  *  DESIGN.md 9 and removed.)
  */
@@ -159,6 +161,18 @@ int sacamd_encode_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles
  * Predict() / Encode() split of the reference's FrameCoder (sac_amd/csrc/framecoder.h). */
 int sacamd_search_frames(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles_io);
 
+/* The DDS search in instalments (ABI 6).  Replaces: the same FrameCoder::Optimize + OptDDS::run_mt / run_single (opt/dds.cpp:33-106) as
+ * sacamd_search_frames, cut into calls of at most max_generations lock-step generations -- the --best preset (cmdline.cpp:127-156: 1000
+ * evaluations of the CostBitplane objective, libsac/cost.h:144-176) is 125 generations of tens of seconds each at full frame size, more than
+ * one call of a time-boxed job holds.  `state` is an opaque blob the caller keeps between calls (every frame's mt19937, best point and
+ * cost, sigma, SSC counters, evaluation count; capacity: sacamd_search_state_bytes): *state_len = 0 starts a search (start point =
+ * profiles_io, or the base profile with cfg.reset), otherwise the search goes on from the blob; on return *state_len = bytes written,
+ * *done = 1 once maxnfunc evaluations are spent, profiles_io = the best profile so far.  The candidates, costs and the final profile are
+ * those of one uninterrupted sacamd_search_frames (same frames staged, same cfg).  DDS only (SACAMD_ERR_ARG for DE / CMA). */
+int sacamd_search_frames_resume(sacamd_ctx *ctx, const sacamd_cfg *cfg, float *profiles_io, int max_generations, uint8_t *state,
+                                long long state_cap, long long *state_len, int *done);
+long long sacamd_search_state_bytes(const sacamd_ctx *ctx);
+
 /* ---- (7) adaptive sub-frame split -------------------------------------------------------------
  * Replaces: Codec::Analyse + AnalyseSparse + PushState (libsac/libsac.cpp:696-780) with SparsePCM::Analyse
  * (libsac/sparse.h:31-96): one read of samples_read samples per channel (planar int32, host memory, un-centred)
@@ -251,10 +265,12 @@ int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
 /* per kernel instance of the two heavy predictor stages, since the last reset: out[(kind*16 + slot)*4 + {0,1,2,3}] =
  * total ms (HIP events on the launch's stream), launches, item-steps processed, algorithmic fp64 flops (FMA = 2,
  * SURVEY.md 8d formula with each item's actual regressor length / tap counts).  kind 0 = OLS: slots 0..7 = capacity
- * classes 16,24,32,40,48,56,64 taps (k_ols<64,NMAX>, one wave) and 96 (k_ols<256,96>); slots 11..14 = the four-wave panel
- * kernels k_ols<256,40..64> the final pass uses for its 33..64-tap items.  kind 1 = cascade layout classes 0..15 (0..6:
- * search layouts, 7..9 and 10..13: canonical-order layouts of the final pass).  out receives 2 * 16 * 4 = 128 entries;
- * cap = capacity of out in doubles (SACAMD_ERR_ARG if smaller).  ABI version 2 (version 1 had no cap and 80 entries). */
+ * classes 16,24,32,40,48,56,64,96 taps.  Which kernel a slot is (kernels_pred.hip: launch_ols, since round 5): slot 0
+ * k_ols_pack<16,16>; slot 1 k_ols_pack<24,32> in the search, k_ols_grid<3> in the final pass; slot 2 k_ols_grid<4>;
+ * slots 3..6 k_ols_grid<5..8> (one wave, matrix 2D-cyclic over the lanes); slot 7 k_ols<256,96> (four waves); slots
+ * 11..14 stay zero unless SACAMD_OLS_GRID=0 selects the retired four-wave panel kernels.  kind 1 = cascade layout classes
+ * 0..15 (0..6: search layouts, 7..9 and 10..13: canonical-order layouts of the final pass).  out receives 2 * 16 * 4 = 128
+ * entries; cap = capacity of out in doubles (SACAMD_ERR_ARG if smaller).  ABI version 2 (version 1 had no cap and 80 entries). */
 int sacamd_class_times(sacamd_ctx *ctx, double *out128, int cap, int reset);
 
 /* Progress of a running sacamd_encode_frames on this context; may be called from another thread while that call

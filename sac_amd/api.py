@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
     "sacamd_decode_frames", "sacamd_comm_unique_id", "sacamd_comm_create", "sacamd_comm_destroy", "sacamd_comm_last_error",
     "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_debug_libm", "sacamd_predictor_streams", "sacamd_get_encoded_variant", "sacamd_get_residuals_map",
+    "sacamd_search_frames_resume", "sacamd_search_state_bytes",
 ]
 
 
@@ -65,7 +66,7 @@ def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, f
 _lib = None
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PredTParam(ctypes.Structure):
@@ -386,6 +387,20 @@ class Context:
         self._chk(self.lib.sacamd_encode_frames(self.h, byref(cfg), _vp(prof), _vp(out), c_longlong(cap), _vp(off)))
         recs = [out[off[f]: off[f + 1]].tobytes() for f in range(self.nframes)]
         return recs, prof
+
+    def search_frames_resume(self, cfg: Cfg, max_generations: int, state=None, profiles=None):
+        """The DDS search in instalments (sacamd_search_frames_resume): -> (best profiles so far, state blob, done)."""
+        prof = np.zeros((self.nframes, NUM_COEFS), np.float32)
+        prof[:] = default_profile()[:, 2] if profiles is None else np.asarray(profiles, np.float32).reshape(self.nframes, NUM_COEFS)
+        self.lib.sacamd_search_state_bytes.restype = c_longlong
+        cap = int(self.lib.sacamd_search_state_bytes(self.h))
+        buf = np.zeros(cap, np.uint8)
+        n = c_longlong(0)
+        if state is not None:
+            buf[: len(state)] = np.frombuffer(state, np.uint8); n = c_longlong(len(state))
+        done = c_int(0)
+        self._chk(self.lib.sacamd_search_frames_resume(self.h, byref(cfg), _vp(prof), int(max_generations), _vp(buf), c_longlong(cap), byref(n), byref(done)))
+        return prof, buf[: n.value].tobytes(), bool(done.value)
 
     def decode_frames(self, recs, framesize):
         """Frame records (bytes, as encode_frames returns them / as they lie in a .sac file) -> (list of PCM arrays

@@ -17,9 +17,11 @@
 #include <map>
 #include <mutex>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <numeric>
 #include <tuple>
 #include <random>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -102,6 +104,7 @@ struct sacamd_ctx {
   std::string err;
   unsigned long long *d_prof = nullptr;   // debug: OLS section counters
   // staged batch
+  bool remap_valid = false;               // the last sacamd_encode ran CalcRemapError (cfg.sparse_pcm)
   int nframes = 0, framesize = 0;
   bool analysed = false, final_done = false, encoded = false;
   std::vector<int> nsamp;
@@ -266,16 +269,35 @@ PcmView view(sacamd_ctx *c) { return PcmView{c->d_pcm.p, c->frame_stride, c->ch_
 // initialises, i.e. at the process's first HIP call.  The pool below needs 14 streams that really run side by side (plus a main
 // stream per context and the decoder's pair), so the library asks for 24 queues when it is LOADED -- before its own first HIP call,
 // which in a C++ host program (sacenc, framecoder.h) is the first one of the process.  A value the user has set stays; a value too
-// small for the pool makes sacamd_ctx_create fail with a message instead of running 13 kernel classes through 4 queues
-// (SACAMD_ALLOW_FEW_QUEUES=1 overrides).  A host that initialised HIP before loading the library must set the variable itself.
+// small for the pool makes sacamd_ctx_create warn (round 6; rounds 4-5 refused).  A host that initialised HIP before loading the
+// library must set the variable itself.
 constexpr int kHwQueuesWanted = 24, kHwQueuesNeeded = 16;
-__attribute__((constructor)) void sacamd_on_load() { (void)setenv("GPU_MAX_HW_QUEUES", "24", /*overwrite=*/0); }
+// Round 6: the constructor records whether the LIBRARY set the variable.  If it did and a HIP-using module was already in the
+// process (torch's libtorch_hip / libc10_hip: the Python host imported torch first), HIP has most likely read the default of 4 already --
+// the check below would pass on the environment string while the process really runs 4 queues -- so that case warns once.  A small value
+// the USER set is the user's decision (A/B scripts do it on purpose): a warning, not a failure.
+bool g_queues_set_by_lib = false, g_hip_host_preloaded = false;
+__attribute__((constructor)) void sacamd_on_load() {
+  if (!std::getenv("GPU_MAX_HW_QUEUES")) {
+    g_queues_set_by_lib = setenv("GPU_MAX_HW_QUEUES", "24", /*overwrite=*/0) == 0;
+    for (const char *lib : {"libtorch_hip.so", "libc10_hip.so"}) {
+      if (void *h = dlopen(lib, RTLD_NOLOAD | RTLD_LAZY)) { g_hip_host_preloaded = true; dlclose(h); }
+    }
+  }
+}
 bool hw_queues_ok(std::string *why) {
-  const char *e = std::getenv("GPU_MAX_HW_QUEUES"), *allow = std::getenv("SACAMD_ALLOW_FEW_QUEUES");
+  static std::once_flag warned;
+  const char *e = std::getenv("GPU_MAX_HW_QUEUES");
   const int have = e ? std::atoi(e) : 4;
-  if (have >= kHwQueuesNeeded || (allow && allow[0] == '1')) return true;
-  if (why) *why = "GPU_MAX_HW_QUEUES=" + std::to_string(have) + ": the stream pool needs >= " + std::to_string(kHwQueuesNeeded) + " hardware queues (unset it or set " + std::to_string(kHwQueuesWanted) + "; SACAMD_ALLOW_FEW_QUEUES=1 to run anyway)";
-  return false;
+  if (g_queues_set_by_lib && g_hip_host_preloaded)
+    std::call_once(warned, [] { std::fprintf(stderr, "sac_amd: GPU_MAX_HW_QUEUES was unset when the library was loaded AFTER a HIP-using module (torch): if HIP was already "
+                                                     "initialised the process runs on the default 4 hardware queues and the stream pool's %d kernel classes share them. "
+                                                     "Export GPU_MAX_HW_QUEUES=%d before the first HIP call (bench.py and sac_amd.api do).\n", sacamd_ctx::kSide, kHwQueuesWanted); });
+  else if (have < kHwQueuesNeeded)
+    std::call_once(warned, [have] { std::fprintf(stderr, "sac_amd: GPU_MAX_HW_QUEUES=%d (set by the caller): the stream pool wants >= %d hardware queues; kernel classes will "
+                                                         "serialise on the ones there are.\n", have, kHwQueuesNeeded); });
+  (void)why;
+  return true;
 }
 
 struct DevStreams {
@@ -654,7 +676,8 @@ void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start
 }  // namespace
 
 // ================================================================== context
-API int sacamd_abi_version(void) { return 5; }   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*); 4: the gather's first all-gather carries 4 words per rank (ranks of different builds must not meet), sacamd_debug_libm
+API int sacamd_abi_version(void) { return 6; }   // 6: sacamd_search_frames_resume, sacamd_search_state_bytes
+// (history)   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*); 4: the gather's first all-gather carries 4 words per rank (ranks of different builds must not meet), sacamd_debug_libm
 
 API void sacamd_default_cfg(sacamd_cfg *cfg) {
   std::memset(cfg, 0, sizeof(*cfg));
@@ -1357,6 +1380,13 @@ API int sacamd_encode(sacamd_ctx *c, const sacamd_cfg *cfg) {
 }
 API int sacamd_search_frames(sacamd_ctx *c, const sacamd_cfg *cfg, float *profiles_io) {
   return guarded(c, "sacamd_search_frames", [&] { return search_frames_body(c, cfg, profiles_io); });
+}
+API int sacamd_search_frames_resume(sacamd_ctx *c, const sacamd_cfg *cfg, float *profiles_io, int max_generations, uint8_t *state, long long state_cap,
+                                    long long *state_len, int *done) {
+  return guarded(c, "sacamd_search_frames_resume", [&] { return search_resume_body(c, cfg, profiles_io, max_generations, state, state_cap, state_len, done); });
+}
+API long long sacamd_search_state_bytes(const sacamd_ctx *c) {     // header + start profiles + per frame: counters, best point, mt19937 as text (624 numbers of <= 10 digits)
+  return c ? 64 + (long long)c->nframes * (kNumCoefs * 4 + 16 + 24 + 56 * 8 + 4 + 7168) : 0;
 }
 API int sacamd_encode_frames(sacamd_ctx *c, const sacamd_cfg *cfg, float *profiles_io, uint8_t *out, long long cap, long long *rec_off) {
   return guarded(c, "sacamd_encode_frames", [&] { return encode_frames_body(c, cfg, profiles_io, out, cap, rec_off); });

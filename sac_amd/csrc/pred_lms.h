@@ -132,13 +132,15 @@ struct LmsLds {
   double *mt[4], *pt[4];                  // CANON: mutab / powtab of each stage, indexed like the rings (ridx(tap)); read once per sample
   double *ring[4];
   double *part;     // [2][NL/64][8]
-  double *bc;       // [8]: wgrad[4], unused
+  double *bc;       // [4]: wgrad of each stage
   double *pin, *pout;
   double *rx, *rw, *rph;     // RLS history / weights mirror / P*x
   double *P;                 // RLS inverse covariance, row l at P + l * kRlsMax (owned by the lanes of wave 2)
-  double *pv;                // stage predictions p[0..4]
+  double *pv;                // stage predictions p[0..3]
   double *exwm;              // expert weights mirror [2][5]
-  double *cst;               // vmu[4], sum_powtab[4]
+  double *cst;               // vmu[4], sum_powtab[4]; [8..15] proj_alpha, 1 - proj_alpha, mu_mix, mu_mix_beta, 1 - mu_mix_beta, lm_alpha, lo, hi (round 6: the
+                             // work-item's ChanParam may alias the kernel's output for all the compiler knows, so p.x inside the sample loop was a
+                             // global_load per sample in the middle of the serial chains)
   double *hs;                // head -> pieces: target, ep[2], pl[5], bp4, rpx; [10] next RLS prediction (wave 2 -> head); [12..13] blend weights smw
   double *libm;              // staged log/exp tables of libm_port.h
   int *sv;
@@ -152,7 +154,7 @@ struct LmsLds {
     for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringlen(cap_of(s, ringcap[s]))) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
     if (CANON) d += 64 + 32 + 64 + 32;
     if (CANON == 3) d += (size_t)(NL / 2) * C::c0;     // mutab of the dot lanes, lane-major per wave
-    d += 2 * (NL / 64) * 8 + 8 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 8 + 10 + 8 + 16 + kLibmLdsDoubles;   // pin/pout: NL samples staged per exchange
+    d += 2 * (NL / 64) * 8 + 4 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 4 + 10 + 16 + 16 + kLibmLdsDoubles;   // part, bc[4], pin/pout, RLS, pv[4], exwm, cst, hs, libm   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + NL * sizeof(int) + 16;
   }
   SA_HD static size_t bytes() {
@@ -173,11 +175,11 @@ struct LmsLds {
     for (int s = 0; s < 4; s++) { mt[s] = pt[s] = nullptr; if (CANON == 1) { mt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; pt[s] = d; d += (size_t)ridx(ringcap[s]) + 1; } }
     if (CANON == 3) { mt[0] = d; d += (size_t)(NL / 2) * C::c0; }
     part = d; d += 2 * (NL / 64) * 8;
-    bc = d; d += 8;
+    bc = d; d += 4;
     pin = d; d += NL; pout = d; d += NL;
     rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
     P = d; d += kRlsMax * kRlsMax;
-    pv = d; d += 8; exwm = d; d += 10; cst = d; d += 8; hs = d; d += 16;
+    pv = d; d += 4; exwm = d; d += 10; cst = d; d += 16; hs = d; d += 16;
     libm = d; d += kLibmLdsDoubles;
     sv = reinterpret_cast<int *>(d);
   }
@@ -393,10 +395,11 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         q_ttap[l] = tt < nst - 1 ? tt : nst - 1;
       }
     }
-    if (l < 8) { L.bc[l] = 0.0; L.pv[l] = 0.0; }
+    if (l < 4) { L.bc[l] = 0.0; L.pv[l] = 0.0; }
     sa_stage_tables(L.libm, l, NL);
 #pragma unroll
     for (int s = 0; s < 4; s++) if (l == s) { L.cst[s] = p.vmu[s]; L.cst[4 + s] = sum_powtab[s]; }
+    if (l == 8) { L.cst[8] = p.proj_alpha; L.cst[9] = 1.0 - p.proj_alpha; L.cst[10] = p.mu_mix; L.cst[11] = p.mu_mix_beta; L.cst[12] = 1.0 - p.mu_mix_beta; L.cst[13] = p.lm_alpha; L.cst[14] = (double)p.lo; L.cst[15] = (double)p.hi; }
     if (l < 10) L.exwm[l] = 1.0 / 5;
     if (l < 16) L.hs[l] = (l == 12 || l == 13) ? 0.5 : 0.0;
     if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }
@@ -428,7 +431,6 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   double smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0, denom = 0.0, inv_alpha = 0.0, phi = 0.0;   // wave 3 / wave 2 uniform state
   bool have_prev = false;
 
-  const double lo = (double)p.lo, hi = (double)p.hi;
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
 #define SA_TICK(i) do { if (prof) { const unsigned long long now_ = E::clock(); tp[i] += now_ - tc; tc = now_; } } while (0)
   if (prof) tc = E::clock();
@@ -744,6 +746,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       bool dec_ok = true;
       ex.wave(0, [&]() {
         const double smw0 = L.hs[12], smw1 = L.hs[13];
+        const double pa = L.cst[8], pa1 = L.cst[9], lo = L.cst[14], hi = L.cst[15];        // proj_alpha, 1 - proj_alpha, Cascade clamp range
         // Cascade::Predict (cascade.h:93-100)
         const double rpx = L.hs[10];                       // dot(rx, rw), left here by wave 2 after its update
         double pl[5], ep[2];
@@ -773,7 +776,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         for (int i = 0; i <= 4; i++) {
           const double ew0 = L.exwm[i], ew1 = L.exwm[5 + i];
           const double wgt = fmax(dot_canon_n<2>([&](int q) { return q ? ew1 : ew0; }, [&](int q) { return q ? smw1 : smw0; }), 0.0);
-          const double px = fma(1.0 - p.proj_alpha, p_prefix, p.proj_alpha * pred);
+          const double px = fma(pa1, p_prefix, pa * pred);
           bp[i] = target - clampd(px, lo, hi);
           p_prefix = fma(wgt, pl[i], p_prefix);
         }
@@ -797,9 +800,9 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const double error = L.hs[0] - L.hs[1 + e];
           const double loss = e ? error : sgnd(error);
           const double grad = loss * L.hs[3 + i];
-          const double beta = p.mu_mix_beta, beta1 = 1.0 - p.mu_mix_beta;
+          const double beta = L.cst[11], beta1 = L.cst[12];
           exeg_r[g] = fma(beta, exeg_r[g], beta1 * grad * grad);
-          const double mu_scaled = p.mu_mix / (sqrt(exeg_r[g]) + 1e-5);
+          const double mu_scaled = L.cst[10] / (sqrt(exeg_r[g]) + 1e-5);
           exw_r[g] = fma(mu_scaled, grad, exw_r[g]);
           L.exwm[l] = exw_r[g];
         }
@@ -812,7 +815,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         const double err2 = rerr * rerr;
         const double R = fmax(S0 - S1, 1e-5);
         const double nis = err2 / (phi + R);
-        const double mm = sa_exp_t(-p.lm_alpha * nis, exptab);
+        const double mm = sa_exp_t(-L.cst[13] * nis, exptab);
         alpha = fma(0.999 - 0.99, mm, 0.99);
         S0 = fma(0.95, S0, (1.0 - 0.95) * err2);
         S1 = fma(0.95, S1, (1.0 - 0.95) * phi);

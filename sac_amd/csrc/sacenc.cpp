@@ -197,11 +197,11 @@ int main(int argc, char **argv) {
       // no --job-tag: take what the launcher provides (the same value on every rank of ONE job); none -> refuse, because with a
       // shared default tag a rank could pick up the id file a crashed run of the same world size left behind and hang in
       // ncclCommInitRank (round-4 advice)
-      for (const char *var : {"SACENC_JOB_TAG", "SLURM_JOB_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"}) {
+      for (const char *var : {"SACENC_JOB_TAG", "SLURM_JOB_ID", "TORCHELASTIC_RUN_ID"}) {   // (not MASTER_PORT: the same for consecutive runs, no protection against a stale file)
         const char *e = std::getenv(var);
         if (e && *e) { unsigned long long h = 1469598103934665603ull; for (const char *q = e; *q; q++) h = (h ^ (unsigned char)*q) * 1099511628211ull; job_tag = h; job_tag_given = true; break; }
       }
-      if (!job_tag_given) { std::cerr << "sacenc: --world > 1 needs --job-tag=N (or SACENC_JOB_TAG / SLURM_JOB_ID / TORCHELASTIC_RUN_ID / MASTER_PORT in the environment), the same on every rank of this job\n"; return 2; }
+      if (!job_tag_given) { std::cerr << "sacenc: --world > 1 needs --job-tag=N (or SACENC_JOB_TAG / SLURM_JOB_ID / TORCHELASTIC_RUN_ID in the environment), the same on every rank of this job\n"; return 2; }
     }
     if (use_comm && !cfg.reset) throw std::runtime_error("frames are sharded across ranks: --opt-reset semantics only");
     sacamd_ctx *ctx = nullptr;

@@ -171,6 +171,33 @@ def main_r6(only=None):
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 
 
+def main_r7(only=None):
+    """tests/golden/ref_golden_r7.npz (round 6): searches at the presets' full lengths (golden_cases.preset_length_cases): record
+    bytes (small frame) or SHA-256 (full-size frame), chosen profile, every search cost."""
+    import hashlib, time
+    from golden_cases import preset_length_cases
+    R = Checker("ref")
+    path = os.path.join(HERE, "ref_golden_r7.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name, (raw, cfg, fs) in preset_length_cases().items():
+        if only and name not in only:
+            continue
+        R.lib.ref_set_parallel_eval(1 if cfg.num_threads > 1 else 0)
+        t = time.time()
+        r = R.encode_frame(raw, cfg, fs, trace=True)
+        out[f"cfg/{name}/raw_sha256"] = np.frombuffer(hashlib.sha256(raw.astype(np.int16).tobytes()).digest(), np.uint8)
+        out[f"cfg/{name}/record_sha256"] = np.frombuffer(hashlib.sha256(r["record"]).digest(), np.uint8)
+        out[f"cfg/{name}/record_len"] = np.array([len(r["record"])], np.int64)
+        if raw.size <= 100000:
+            out[f"cfg/{name}/record"] = np.frombuffer(r["record"], np.uint8)
+        out[f"cfg/{name}/profile"] = r["profile"]
+        out[f"cfg/{name}/trace_cost"] = r["trace_cost"]
+        out[f"cfg/{name}/wall_seconds"] = np.array([time.time() - t])
+        print(name, len(r["record"]), "bytes", len(r["trace_cost"]), "costs", round(time.time() - t, 1), "s", flush=True)
+        np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
 def main():
     R = Checker("ref")
     out = {}
@@ -258,6 +285,8 @@ if __name__ == "__main__":
         main_r4()
     elif "--r5" in sys.argv:
         main_r5()
+    elif "--r7" in sys.argv:
+        main_r7([a for a in sys.argv[1:] if not a.startswith("--")] or None)
     elif "--r6" in sys.argv:
         main_r6([a for a in sys.argv[1:] if not a.startswith("--")] or None)
     else:

@@ -163,6 +163,20 @@ def config34_full_cases():
     return c
 
 
+def preset_length_cases():
+    """Round 6: searches at the presets' FULL lengths that one GPU test can afford.
+    best_s16_8k_e1000: --best (cmdline.cpp:127-156: fraction 0.5, E = 1000, sigma 0.25, CostBitplane) with --opt-cfg=dds,8 on a
+      reduced frame (8 kHz, 5 000 samples: the whole frame is the search window) -- the 125-generation Bitplane-cost trajectory
+      at the preset's length;
+    full_s16_high_single_e100: --high as the reference runs it WITHOUT --opt-cfg (OptDDS::run_single, opt/dds.cpp:33-60,
+      num_threads = 0): 100 sequential evaluations on one full-size 20-s stereo frame.
+    name -> (raw PCM, FrameCfg, max frame size)."""
+    c = {}
+    c["best_s16_8k_e1000"] = (synth_pcm(5000, 2, 3300, RATE), frame_cfg("best", num_threads=8), FRAMESIZE)
+    c["full_s16_high_single_e100"] = (synth_pcm(20 * FULL_RATE, 2, 3400, FULL_RATE), frame_cfg("high", num_threads=0), FULL_FRAMESIZE)
+    return c
+
+
 def subframe_cases():
     """name -> (pcm [nch,n] int32 raw, blocksamples, min_frame_length): material whose 3-"second"
     blocks alternate between dense and sparse (quantised) PCM, for Codec::Analyse / PushState."""

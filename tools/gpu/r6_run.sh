@@ -19,6 +19,17 @@ case "$1" in
     timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_sweep2.json 2> $O/bench_768_sweep2.err
     tail -c 2500 $O/bench_768_sweep2.json
     ;;
+  call3)    # loop-invariant parameters in LDS; new full-preset / instalment / run_single tests; one 768-frame step
+    timeout 300 python tests/gpu_latency.py > $O/latency_sections_call3.txt 2>&1; grep -B1 "k=4" $O/latency_sections_call3.txt | cut -c1-150 | head -4; grep -A1 "3383" $O/latency_sections_call3.txt | cut -c1-150
+    timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_call3.txt 2>&1; grep "16 taps" $O/throughput_lms_call3.txt | cut -c1-160
+    timeout 1500 python -m pytest tests -q -m gpu -x --durations=8 -k "instalments or run_single or full_preset or predictor_class or evaluate_costs or both_coder_variants or frame_records" > $O/gputests_03_call3_subset.log 2>&1
+    tail -14 $O/gputests_03_call3_subset.log
+    timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_call3.json 2> $O/bench_768_call3.err
+    python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r06/bench_768_call3.json")); print(d["value"], d["ms_per_step"], d["bps"], d["kernel_ms"])
+PY
+    ;;
   bench768)
     timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_$2.json 2> $O/bench_768_$2.err
     tail -c 1500 $O/bench_768_$2.json
