@@ -470,14 +470,27 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const int st = q_sc[l] >> 3;
           const double wg = L.bc[st];
           const double *mtl = L.mt[0] + (size_t)((l >> 6) * J3) * 64 + (l & 63);
-#pragma unroll
-          for (int j = 0; j < J3; j++) {
-            const double xn = rg[bn + 9 * j], xo = rg[bo + 9 * j];
-            double w = fma(mtl[j * 64], wg * xo, W[l].v[j]);       // mutab is 0 at empty positions: the weight stays 0
+          // Round 6: written as a software pipeline (history / mutab loads of position j + 3 in flight under position j's update,
+          // a scheduling fence per position).  Left to itself the scheduler issues all 3 J loads of the lane first -- 6 J transient
+          // registers on top of the 4 J that W and XD need anyway: 108 registers of the 17-position layout, 148 of the 33-position
+          // one and 288 B of the 49-position one went to scratch, reloaded in the middle of every sample.
+          constexpr int GA = 3 < J3 ? 3 : J3;
+          double bo_[GA], bm_[GA];
+          auto ldj = [&](auto JC) {
+            constexpr int j = decltype(JC)::value;
+            XD[l].v[j] = rg[bn + 9 * j]; bo_[j % GA] = rg[bo + 9 * j]; bm_[j % GA] = mtl[j * 64];
+          };
+          static_for<0, GA>(ldj);
+          static_for<0, J3>([&](auto JC) {
+            constexpr int j = decltype(JC)::value;
+            const double xo = bo_[j % GA], mt = bm_[j % GA];
+            if constexpr (j + GA < J3) ldj(std::integral_constant<int, j + GA>{});
+            double w = fma(mt, wg * xo, W[l].v[j]);       // mutab is 0 at empty positions: the weight stays 0
             w = clampd(w, -10.0, 10.0);
+            SA_PIN_F64(w);
             W[l].v[j] = w;
-            XD[l].v[j] = xn;
-          }
+            SA_SCHED_FENCE();
+          });
           {   // the chain's tail tap (first lane of the chain; elsewhere its mutab is 0)
             int in = q_pos[l] + q_ttap[l]; if (in >= q_cap[l]) in -= q_cap[l];
             const double xo = rg[ridx(in + 1)];
@@ -489,11 +502,19 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         } else {
           // taps 4 (k0 + j) + c4: even j at ridx(u0) + 9 (j/2), odd j at ridx(u0 + 4) + 9 (j/2)
           const int be = ridx(u0), bd = ridx(u0 + 4);
-#pragma unroll
-          for (int j = 0; j < J3; j++) {
-            const double xs = rg[((j & 1) ? bd : be) + 9 * (j >> 1)];
-            XD[l].v[j] = xs * xs;
-          }
+          constexpr int GA = 4 < J3 ? 4 : J3;                 // same pipeline: the square of position j under the loads of j + 1 .. j + 4
+          double bx_[GA];
+          auto ldj = [&](auto JC) { constexpr int j = decltype(JC)::value; bx_[j % GA] = rg[((j & 1) ? bd : be) + 9 * (j >> 1)]; };
+          static_for<0, GA>(ldj);
+          static_for<0, J3>([&](auto JC) {
+            constexpr int j = decltype(JC)::value;
+            const double xs = bx_[j % GA];
+            if constexpr (j + GA < J3) ldj(std::integral_constant<int, j + GA>{});
+            double q = xs * xs;
+            SA_PIN_F64(q);
+            XD[l].v[j] = q;
+            SA_SCHED_FENCE();
+          });
         }
         q_acc[l] = 0.0;
       });

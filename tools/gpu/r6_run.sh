@@ -30,6 +30,16 @@ import json
 d=json.load(open("gpurun_out/r06/bench_768_call3.json")); print(d["value"], d["ms_per_step"], d["bps"], d["kernel_ms"])
 PY
     ;;
+  call4)    # lane-map canonical cascade as a software pipeline (no spills): parity, per-layout latency, final pass in isolation, 1536-frame step
+    timeout 900 python -m pytest tests -q -m gpu -x -k "canonical or predictor_stages or frame_records or decoder_inverts or full_size_records" > $O/gputests_04_canon.log 2>&1; tail -3 $O/gputests_04_canon.log
+    for t in 1280,256,32,4 2500,1200,600,128 3383,1168,614,273 5400,64,16,8 6900,64,8,8; do timeout 200 python tests/gpu_dbg_canon.py $t 6000; done > $O/canon_latency_call4.txt 2>&1; cat $O/canon_latency_call4.txt
+    timeout 600 python tests/gpu_finalpass.py 256 60000 "16/32;32/48;24/64" > $O/finalpass_call4.txt 2>&1; cat $O/finalpass_call4.txt | cut -c1-170
+    timeout 1500 python bench.py --frames 1536 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_1536_call4.json 2> $O/bench_1536_call4.err
+    python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r06/bench_1536_call4.json")); print(d["value"], d["ms_per_step"], d["bps"], d["kernel_ms"]); print({k:round(v/1e3,1) for k,v in d["kernel_instances_ms"].items()})
+PY
+    ;;
   bench768)
     timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_$2.json 2> $O/bench_768_$2.err
     tail -c 1500 $O/bench_768_$2.json
