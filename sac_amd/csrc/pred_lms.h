@@ -332,7 +332,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // they share four registers (the tap state already fills the register file in the large classes);
   // the RLS matrix P lives in LDS and is held in registers only while wave 2 works on it.
   typename E::template Reg<double> mr0, mr1, mr2, mr3;
-  auto &dots_r = mr0; auto &spow_r = mr1;                                   // wave 0, lanes 16..19
+  auto &dots_r = mr0; auto &spow_r = mr1; auto &vmu_r = mr2; auto &spt_r = mr3;   // wave 0, lanes 16..19 (vmu / sum_powtab of the lane's stage: constants)
   auto &exw_r = mr0; auto &exeg_r = mr1;                                    // wave 1, lanes 0..9
   auto &rw_r = mr0; auto &ph_r = mr1; auto &xo_r = mr2; auto &rcp_r = mr3;  // wave 2
   auto &exz_r = mr0;                                                        // wave 3
@@ -405,6 +405,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }
     mr0[l] = (l >> 6) == 1 ? 1.0 / 5 : 0.0;   // wave 1: LS_ADA expert weights start at 1/5
     mr1[l] = 0.0; mr2[l] = 0.0; mr3[l] = 0.0;
+    if (l >= 16 && l < 20) { mr2[l] = p.vmu[l - 16]; mr3[l] = sum_powtab[l - 16]; }
     if (l < kRlsMax * kRlsMax) L.P[l] = (l / kRlsMax == l % kRlsMax) ? 1.0 : 0.0;
   });
   ex.sync();
@@ -687,17 +688,35 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const double *prow = L.P + l * kRlsMax;   // (this lane's own row: no synchronisation with the update above)
           ph_r[g] = dot_canon_m(m, [&](int j) { return prow[j]; }, [&](int j) { return L.rx[j]; });
           L.rph[l] = ph_r[g];
+          xo_r[g] = l > 0 ? L.rx[l - 1] : 0.0;        // what RollBack (rls.cpp:64) moves into this lane after the update: read here, off the post-head chain
         }
       });
       ex.wsync();
       ex.wave(2, [&]() { phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8); });
+      // Wave 0 (round 6): every LDS input of the head -- last step's blend weights, RLS prediction and expert weights, the constants, this
+      // sample's p_lpc and value -- is requested HERE, together with the stage totals' loads: one LDS round trip for the whole head where
+      // the compiler's placement (loads next to their first use, under register pressure) had eight in a row.
+      double h_smw0 = 0.0, h_smw1 = 0.0, h_rpx = 0.0, h_pa = 0.0, h_pa1 = 0.0, h_lo = 0.0, h_hi = 0.0, h_plpc = 0.0, h_exw[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      int h_sv = 0;
+      ex.wave(0, [&]() {
+        h_smw0 = L.hs[12]; h_smw1 = L.hs[13]; h_rpx = L.hs[10];
+        h_pa = L.cst[8]; h_pa1 = L.cst[9]; h_lo = L.cst[14]; h_hi = L.cst[15];
+#pragma unroll
+        for (int i = 0; i < 10; i++) h_exw[i] = L.exwm[i];
+        if (!dec) { h_plpc = L.pin[tt]; h_sv = L.sv[tt]; }
+      });
       ex.wave_par(0, [&](int l) {
         if (l >= 16 && l < 20) {   // cross-wave totals of stage l-16, waves in order (lanes 16..19 own the stage gains)
           const int s = l - 16;
           double a, b;
           if constexpr (!CANON) {
-            a = L.part[(par * NW) * 8 + s]; b = L.part[(par * NW) * 8 + 4 + s];
-            for (int w = 1; w < NW; w++) { a = a + L.part[(par * NW + w) * 8 + s]; b = b + L.part[(par * NW + w) * 8 + 4 + s]; }
+            double pa_[NW], pb_[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) { pa_[w] = L.part[(par * NW + w) * 8 + s]; pb_[w] = L.part[(par * NW + w) * 8 + 4 + s]; }
+            SA_SCHED_FENCE();                  // all partial sums requested before the first addition
+            a = pa_[0]; b = pb_[0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) { a = a + pa_[w]; b = b + pb_[w]; }
           } else {
             // slmath::dot: sum1 + sum2 lane-wise, ((b0+b1)+b2)+b3, += transform_reduce tail; calc_s2pow alike.
             // The rings are addressed as offsets from ring[0] (one LDS base, no pointer select) and every load of
@@ -759,29 +778,29 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
               b = b + init;
             }
           }
-          dots_r[l] = a; spow_r[l] = b; L.pv[s] = a;
+          dots_r[l] = a; spow_r[l] = b;      // (the head takes the stage predictions from these lanes by v_readlane: no LDS hand-over)
         }
       });
-      ex.wsync();
       double bp[5] = {0, 0, 0, 0, 0};
       bool dec_ok = true;
       ex.wave(0, [&]() {
-        const double smw0 = L.hs[12], smw1 = L.hs[13];
-        const double pa = L.cst[8], pa1 = L.cst[9], lo = L.cst[14], hi = L.cst[15];        // proj_alpha, 1 - proj_alpha, Cascade clamp range
+        const double smw0 = h_smw0, smw1 = h_smw1;
+        const double pa = h_pa, pa1 = h_pa1, lo = h_lo, hi = h_hi;        // proj_alpha, 1 - proj_alpha, Cascade clamp range
         // Cascade::Predict (cascade.h:93-100)
-        const double rpx = L.hs[10];                       // dot(rx, rw), left here by wave 2 after its update
+        const double rpx = h_rpx;                          // dot(rx, rw), left in hs[10] by wave 2 after its update
         double pl[5], ep[2];
-        for (int i = 0; i < 4; i++) pl[i] = L.pv[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) pl[i] = ex.lane_bcast(dots_r, 16 + i);
         pl[4] = rpx;
-        for (int e = 0; e < 2; e++) ep[e] = dot_canon_n<5>([&](int i) { return pl[i]; }, [&](int i) { return L.exwm[5 * e + i]; });
+        for (int e = 0; e < 2; e++) ep[e] = dot_canon_n<5>([&](int i) { return pl[i]; }, [&](int i) { return h_exw[5 * e + i]; });
         const double pred = dot_canon_n<2>([&](int i) { return i ? ep[1] : ep[0]; }, [&](int i) { return i ? smw1 : smw0; });
         // The OLS prediction joins here; then the target of all updates, val - p_lpc (pred.cpp:43).  Decoder: p_lpc comes from
         // the OLS kernel of this channel running beside this one, the sum goes to the bias kernel, whose decoded sample comes back.
         double plpc, target;
         if (!dec) {
-          plpc = L.pin[tt];
+          plpc = h_plpc;
           L.pout[tt] = plpc + pred;
-          target = (double)L.sv[tt] - plpc;
+          target = (double)h_sv - plpc;
         } else {
           const int t = t0 + tt;
           dec_ok = sa_wait_ge(dec->prog_in, t + 1, dec->fail);
@@ -795,7 +814,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         double p_prefix = 0.0;
 #pragma unroll
         for (int i = 0; i <= 4; i++) {
-          const double ew0 = L.exwm[i], ew1 = L.exwm[5 + i];
+          const double ew0 = h_exw[i], ew1 = h_exw[5 + i];
           const double wgt = fmax(dot_canon_n<2>([&](int q) { return q ? ew1 : ew0; }, [&](int q) { return q ? smw1 : smw0; }), 0.0);
           const double px = fma(pa1, p_prefix, pa * pred);
           bp[i] = target - clampd(px, lo, hi);
@@ -847,7 +866,6 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         const int l = g & 63;
         if (l < m) {
           rw_r[g] = fma(rerr, denom * ph_r[g], rw_r[g]);
-          xo_r[g] = l > 0 ? L.rx[l - 1] : 0.0;
         }
       });
       ex.wsync();
@@ -886,7 +904,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           // one LDS base + offset: a select among the four ring pointers becomes a load through a selected ADDRESS
           // inside the LmsLds object, which pins that object (and every pointer in it) in scratch memory
           double *rg = L.ring[0] + ((sl >= 1 ? ro1 : 0) + (sl >= 2 ? ro2 : 0) + (sl >= 3 ? ro3 : 0));
-          L.bc[sl] = L.cst[sl] * (bps - dots_r[l]) * L.cst[4 + sl] / (spow_r[l] + 1.0);
+          L.bc[sl] = vmu_r[l] * (bps - dots_r[l]) * spt_r[l] / (spow_r[l] + 1.0);
           int np = ps - 1; if (np < 0) np += cs;
           rg[ridx(np)] = bps;
           if (LM ? np < EXT3 : np == 0) rg[ridx(cs + np)] = bps;        // mirror: ring[in + 1] (lane-map layout: a lane's whole window) needs no wrap in the sweep
