@@ -260,7 +260,7 @@ template <> struct LmsCfg<6> { static constexpr int ROUNDS = 1; using C = LmsY; 
 template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
 template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
 template <> struct LmsCfg<9> { using C = LmsK; static constexpr int NL = 256, MINB = 1, ROUNDS = 4; };
-template <> struct LmsCfg<10> { using C = LmsP17; static constexpr int NL = 256, MINB = 3, ROUNDS = 1; };
+template <> struct LmsCfg<10> { using C = LmsP17; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };   // (round 6: three per CU = 168 registers spilled 56 of them into the sample loop)
 template <> struct LmsCfg<11> { using C = LmsP33; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
 template <> struct LmsCfg<12> { using C = LmsP49; static constexpr int NL = 256, MINB = 1, ROUNDS = 1; };
 template <> struct LmsCfg<13> { using C = LmsP33; static constexpr int NL = 512, MINB = 2, ROUNDS = 1; };
@@ -337,7 +337,7 @@ int lms_max_wg_per_cu(int lms_class) {
     case 0: return LmsCfg<0>::MINB > 2 ? LmsCfg<0>::MINB : 2;
     case 1: return LmsCfg<1>::MINB; case 3: return LmsCfg<3>::MINB; case 4: return LmsCfg<4>::MINB;
     case 5: return LmsCfg<5>::MINB; case 6: return LmsCfg<6>::MINB;
-    case 10: return 3;
+    case 10: return LmsCfg<10>::MINB;
     case 2: case 9: case 12: case 13: return 1;
     default: return 2;
   }

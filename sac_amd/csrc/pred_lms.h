@@ -109,6 +109,11 @@ SA_HD bool canon3_fits(const int *vn, int J, int D) {
 // lane's window of J positions (stride 8 or 4) never wraps: one base address per lane and sample, immediate offsets
 SA_HD constexpr int canon3_ext(int J) { return 8 * J + 8; }
 
+// f(std::integral_constant<int, M>{}) for the run-time RLS order m = M in 1..kRlsMax (uniform branch; everything inside has compile-time sizes)
+template <int M = 1, class F>
+SA_HD void rls_dispatch(int m, F &&f) {
+  if constexpr (M <= kRlsMax) { if (m == M) f(std::integral_constant<int, M>{}); else rls_dispatch<M + 1>(m, f); }
+}
 // P-row dot of the RLS stage with a run-time order 1..10 but compile-time unrolling
 template <class A, class B>
 SA_HD double dot_canon_m(int m, A a, B b) {
@@ -334,7 +339,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   typename E::template Reg<double> mr0, mr1, mr2, mr3;
   auto &dots_r = mr0; auto &spow_r = mr1; auto &vmu_r = mr2; auto &spt_r = mr3;   // wave 0, lanes 16..19 (vmu / sum_powtab of the lane's stage: constants)
   auto &exw_r = mr0; auto &exeg_r = mr1;                                    // wave 1, lanes 0..9
-  auto &rw_r = mr0; auto &ph_r = mr1; auto &xo_r = mr2; auto &rcp_r = mr3;  // wave 2
+  auto &rw_r = mr0; auto &ph_r = mr1; auto &x_r = mr2; auto &rcp_r = mr3;   // wave 2, lane l < lm_n: RLS weight w[l], (P x)[l], history x[l]; lanes 0, 1: reciprocals
   auto &exz_r = mr0;                                                        // wave 3
   ex.par([&](int l) {
     const double *tp = tab;
@@ -402,7 +407,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     if (l == 8) { L.cst[8] = p.proj_alpha; L.cst[9] = 1.0 - p.proj_alpha; L.cst[10] = p.mu_mix; L.cst[11] = p.mu_mix_beta; L.cst[12] = 1.0 - p.mu_mix_beta; L.cst[13] = p.lm_alpha; L.cst[14] = (double)p.lo; L.cst[15] = (double)p.hi; }
     if (l < 10) L.exwm[l] = 1.0 / 5;
     if (l < 16) L.hs[l] = (l == 12 || l == 13) ? 0.5 : 0.0;
-    if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }
+    if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }     // (unused since round 6: the RLS vectors live in wave 2's registers)
     mr0[l] = (l >> 6) == 1 ? 1.0 / 5 : 0.0;   // wave 1: LS_ADA expert weights start at 1/5
     mr1[l] = 0.0; mr2[l] = 0.0; mr3[l] = 0.0;
     if (l >= 16 && l < 20) { mr2[l] = p.vmu[l - 16]; mr3[l] = sum_powtab[l - 16]; }
@@ -671,28 +676,42 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       //   wave 1  LS_ADA expert weights            wave 2  RLS / ALC            wave 3  BlendExp softmax
       // The RLS P-matrix update is deferred until after the next sweep's barrier, where it hides
       // under wave 0's head.
-      if (have_prev) {
-        ex.wave_par(2, [&](int g) {   // P update of row l (rls.cpp:47-56) of the PREVIOUS step
-          const int l = g & 63;
-          if (l < m) {
-            double *prow = L.P + l * kRlsMax;
+      // Round 6.  Per-wave section counters showed that THIS is the sample's critical path, not wave 0's head: wave 2 needed 2 100
+      // cycles from the sweep's barrier to barrier H (wave 0: 1 500) and 2 000 more behind it, nearly all of it LDS round trips -- P row
+      // load / store / reload, the RLS history, P x and the weights each travelled through LDS between lanes that sit in ONE wave.  Now lane
+      // l of wave 2 keeps x[l], w[l] and (P x)[l] in registers, what a dot product needs from the other lanes comes by v_readlane (uniform
+      // values, scalar registers), the history rolls by one DPP shift, and only the lane's own P row is read and written in LDS, once.
+      // Same operations in the same order (dot_canon_n<M> == dot_canon for M terms): bit-identical.
+      rls_dispatch(m, [&](auto MC) {
+        constexpr int M = decltype(MC)::value;
+        double xu[M], phu[M];
+        ex.wave(2, [&]() {
 #pragma unroll
-            for (int j = 0; j < kRlsMax; j++)
-              if (j < m) prow[j] = fma(-denom, ph_r[g] * L.rph[j], prow[j]) * inv_alpha;
+          for (int j = 0; j < M; j++) { xu[j] = ex.lane_bcast(x_r, 128 + j); phu[j] = ex.lane_bcast(ph_r, 128 + j); }    // RLS history; P x of the PREVIOUS step
+        });
+        ex.wave_par(2, [&](int g) {
+          const int l = g & 63;
+          if (l < M) {
+            double *prow = L.P + l * kRlsMax;
+            double pr[M];
+#pragma unroll
+            for (int j = 0; j < M; j++) pr[j] = prow[j];
+            if (have_prev) {            // P update of row l (rls.cpp:47-56) of the PREVIOUS step, deferred to here where it hides under wave 0's head
+              const double phl = ph_r[g];
+#pragma unroll
+              for (int j = 0; j < M; j++) { pr[j] = fma(-denom, phl * phu[j], pr[j]) * inv_alpha; prow[j] = pr[j]; }
+            }
+            // ph = P x, row l (rls.cpp:33): needs only P and the RLS history, both final by now
+            ph_r[g] = dot_canon_n<M>([&](int j) { return pr[j]; }, [&](int j) { return xu[j]; });
           }
         });
-      }
-      ex.wave_par(2, [&](int g) {
-        const int l = g & 63;
-        if (l < m) {   // ph = P x, row l (rls.cpp:33): needs only P and the RLS history, both final by now
-          const double *prow = L.P + l * kRlsMax;   // (this lane's own row: no synchronisation with the update above)
-          ph_r[g] = dot_canon_m(m, [&](int j) { return prow[j]; }, [&](int j) { return L.rx[j]; });
-          L.rph[l] = ph_r[g];
-          xo_r[g] = l > 0 ? L.rx[l - 1] : 0.0;        // what RollBack (rls.cpp:64) moves into this lane after the update: read here, off the post-head chain
-        }
+        ex.wave(2, [&]() {
+          double p2[M];
+#pragma unroll
+          for (int j = 0; j < M; j++) p2[j] = ex.lane_bcast(ph_r, 128 + j);
+          phi = fmax(dot_canon_n<M>([&](int j) { return xu[j]; }, [&](int j) { return p2[j]; }), 1e-8);
+        });
       });
-      ex.wsync();
-      ex.wave(2, [&]() { phi = fmax(dot_canon(L.rx, L.rph, m), 1e-8); });
       // Wave 0 (round 6): every LDS input of the head -- last step's blend weights, RLS prediction and expert weights, the constants, this
       // sample's p_lpc and value -- is requested HERE, together with the stage totals' loads: one LDS round trip for the whole head where
       // the compiler's placement (loads next to their first use, under register pressure) had eight in a row.
@@ -849,9 +868,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       });
       // ---- wave 2: RLS::Update + ALC (rls.cpp:28-56, rls.h:21-39) except the P update (deferred);
       // ph = P x and phi were computed before the barrier (they do not depend on this step's prediction)
-      double rerr = 0.0, alpha = 0.0;
+      double rerr = 0.0, alpha = 0.0, rbp4 = 0.0;
       ex.wave(2, [&]() {
-        rerr = L.hs[8] - L.hs[9];
+        rbp4 = L.hs[8];
+        rerr = rbp4 - L.hs[9];
         const double err2 = rerr * rerr;
         const double R = fmax(S0 - S1, 1e-5);
         const double nis = err2 / (phi + R);
@@ -862,21 +882,18 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       });
       ex.wave_par(2, [&](int g) { if ((g & 63) < 2) rcp_r[g] = 1.0 / ((g & 63) == 0 ? alpha + phi : alpha); });   // both reciprocals in one instruction stream
       ex.wave(2, [&]() { denom = ex.lane_bcast(rcp_r, 128); inv_alpha = ex.lane_bcast(rcp_r, 129); });
-      ex.wave_par(2, [&](int g) {
-        const int l = g & 63;
-        if (l < m) {
-          rw_r[g] = fma(rerr, denom * ph_r[g], rw_r[g]);
-        }
-      });
-      ex.wsync();
-      ex.wave_par(2, [&](int g) {
-        const int l = g & 63;
-        if (l < m) { L.rw[l] = rw_r[g]; L.rx[l] = l == 0 ? L.hs[8] : xo_r[g]; }   // RollBack(x, val), rls.cpp:64
-      });
-      ex.wsync();
-      ex.wave(2, [&]() {   // RLS::Predict of the NEXT step (rls.cpp:21-26): its inputs are final now
-        const double rpx_next = dot_canon(L.rx, L.rw, m);
-        if (ex.is_lane0w()) L.hs[10] = rpx_next;
+      ex.wave_par(2, [&](int g) { if ((g & 63) < m) rw_r[g] = fma(rerr, denom * ph_r[g], rw_r[g]); });
+      ex.wave_shift_up1(2, x_r);                                                              // RollBack(x, val), rls.cpp:64: x[l] <- x[l-1] ...
+      ex.wave_par(2, [&](int g) { if ((g & 63) == 0) x_r[g] = rbp4; });                       // ... and x[0] <- val (the RLS stage's target bp[4])
+      rls_dispatch(m, [&](auto MC) {     // RLS::Predict of the NEXT step (rls.cpp:21-26): its inputs are final now
+        constexpr int M = decltype(MC)::value;
+        ex.wave(2, [&]() {
+          double xu[M], wu[M];
+#pragma unroll
+          for (int j = 0; j < M; j++) { xu[j] = ex.lane_bcast(x_r, 128 + j); wu[j] = ex.lane_bcast(rw_r, 128 + j); }
+          const double rpx_next = dot_canon_n<M>([&](int j) { return xu[j]; }, [&](int j) { return wu[j]; });
+          if (ex.is_lane0w()) L.hs[10] = rpx_next;
+        });
       });
       // ---- wave 3: BlendExp<RunSumEMA>::Update (blend.h:31-90)
       double zm[2] = {0, 0}, maxz = 0.0;
@@ -921,7 +938,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       SA_TICK(7);
     }
   }
-  if (prof) ex.par([&](int l) { if (l == 0) for (int i = 0; i < 8; i++) prof[8 + i] = tp[i]; });
+#ifndef SACAMD_EXP_PROF_WAVE
+#define SACAMD_EXP_PROF_WAVE 0          // build-time knob (tools/build_variant.sh): the wave whose section counters are reported (every wave keeps its own)
+#endif
+  if (prof) ex.par([&](int l) { if (l == 64 * SACAMD_EXP_PROF_WAVE) for (int i = 0; i < 8; i++) prof[8 + i] = tp[i]; });
 #undef SA_TICK
   // flush the last chunk
   if (!dec) ex.par([&](int l) {

@@ -122,6 +122,8 @@ struct ExecEmu {
   template <int GL, class R> void grp_bcast_col(Reg<double> &dst, const R &src, int col, int k) { for (int l = 0; l < NL; l++) dst[l] = src[(l / GL) * GL + k].v[col]; }
   // every lane takes the value of lane-1 (lane 0 keeps its own): DPP wave_shr:1 on the device
   void shift_up1(Reg<double> &r) { for (int l = NL - 1; l > 0; l--) r[l] = r[l - 1]; }
+  // the same inside wave w only (its lane 0 keeps its value; the other waves' registers are untouched)
+  void wave_shift_up1(int w, Reg<double> &r) { for (int l = 64 * w + 63; l > 64 * w; l--) r[l] = r[l - 1]; }
   // uniform code: fma(value lane Q of the calling lane's row of 16 lanes holds in r, w, s) resp. that value itself.  The device runs
   // uniform code on all lanes, every row of 16 holding the same 16 values (the emulator's single instance stands for row 0).
   template <int Q> double row_bcast_fma(const Reg<double> &r, double w, double s) { return fma(r[Q], w, s); }
@@ -271,6 +273,7 @@ struct ExecDev {
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
     r.v = __hiloint2double(hi, lo);
   }
+  SA_D void wave_shift_up1(int w, Reg<double> &r) { if ((tid() >> 6) == w) shift_up1(r); }
   // DP-ALU DPP (gfx90a+): src0 of the instruction = lane Q of the reading lane's row of 16 lanes; ONE instruction per term of a
   // serial fp64 chain whose operands arrive sixteen to a register (pred_ols_grid.h: backward substitution).  All lanes must be
   // active (a disabled source lane is not read).
