@@ -715,13 +715,11 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       // Wave 0 (round 6): every LDS input of the head -- last step's blend weights, RLS prediction and expert weights, the constants, this
       // sample's p_lpc and value -- is requested HERE, together with the stage totals' loads: one LDS round trip for the whole head where
       // the compiler's placement (loads next to their first use, under register pressure) had eight in a row.
-      double h_smw0 = 0.0, h_smw1 = 0.0, h_rpx = 0.0, h_pa = 0.0, h_pa1 = 0.0, h_lo = 0.0, h_hi = 0.0, h_plpc = 0.0, h_exw[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double h_smw0 = 0.0, h_smw1 = 0.0, h_rpx = 0.0, h_pa = 0.0, h_pa1 = 0.0, h_lo = 0.0, h_hi = 0.0, h_plpc = 0.0;
       int h_sv = 0;
       ex.wave(0, [&]() {
         h_smw0 = L.hs[12]; h_smw1 = L.hs[13]; h_rpx = L.hs[10];
         h_pa = L.cst[8]; h_pa1 = L.cst[9]; h_lo = L.cst[14]; h_hi = L.cst[15];
-#pragma unroll
-        for (int i = 0; i < 10; i++) h_exw[i] = L.exwm[i];
         if (!dec) { h_plpc = L.pin[tt]; h_sv = L.sv[tt]; }
       });
       ex.wave_par(0, [&](int l) {
@@ -807,11 +805,13 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         const double pa = h_pa, pa1 = h_pa1, lo = h_lo, hi = h_hi;        // proj_alpha, 1 - proj_alpha, Cascade clamp range
         // Cascade::Predict (cascade.h:93-100)
         const double rpx = h_rpx;                          // dot(rx, rw), left in hs[10] by wave 2 after its update
-        double pl[5], ep[2];
+        double pl[5], ep[2], exw[10];      // (the ten expert weights are loaded here, not with the early batch: 20 registers live across the totals cost more in spills than the round trip saves)
+#pragma unroll
+        for (int i = 0; i < 10; i++) exw[i] = L.exwm[i];
 #pragma unroll
         for (int i = 0; i < 4; i++) pl[i] = ex.lane_bcast(dots_r, 16 + i);
         pl[4] = rpx;
-        for (int e = 0; e < 2; e++) ep[e] = dot_canon_n<5>([&](int i) { return pl[i]; }, [&](int i) { return h_exw[5 * e + i]; });
+        for (int e = 0; e < 2; e++) ep[e] = dot_canon_n<5>([&](int i) { return pl[i]; }, [&](int i) { return exw[5 * e + i]; });
         const double pred = dot_canon_n<2>([&](int i) { return i ? ep[1] : ep[0]; }, [&](int i) { return i ? smw1 : smw0; });
         // The OLS prediction joins here; then the target of all updates, val - p_lpc (pred.cpp:43).  Decoder: p_lpc comes from
         // the OLS kernel of this channel running beside this one, the sum goes to the bias kernel, whose decoded sample comes back.
@@ -833,7 +833,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         double p_prefix = 0.0;
 #pragma unroll
         for (int i = 0; i <= 4; i++) {
-          const double ew0 = h_exw[i], ew1 = h_exw[5 + i];
+          const double ew0 = exw[i], ew1 = exw[5 + i];
           const double wgt = fmax(dot_canon_n<2>([&](int q) { return q ? ew1 : ew0; }, [&](int q) { return q ? smw1 : smw0; }), 0.0);
           const double px = fma(pa1, p_prefix, pa * pred);
           bp[i] = target - clampd(px, lo, hi);
