@@ -407,7 +407,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     if (l == 8) { L.cst[8] = p.proj_alpha; L.cst[9] = 1.0 - p.proj_alpha; L.cst[10] = p.mu_mix; L.cst[11] = p.mu_mix_beta; L.cst[12] = 1.0 - p.mu_mix_beta; L.cst[13] = p.lm_alpha; L.cst[14] = (double)p.lo; L.cst[15] = (double)p.hi; }
     if (l < 10) L.exwm[l] = 1.0 / 5;
     if (l < 16) L.hs[l] = (l == 12 || l == 13) ? 0.5 : 0.0;
-    if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }     // (unused since round 6: the RLS vectors live in wave 2's registers)
+    if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }     // (rx, rw unused since round 6: the RLS vectors live in wave 2's registers; rph = the wave-uniform state `us`, all zero at the start)
     mr0[l] = (l >> 6) == 1 ? 1.0 / 5 : 0.0;   // wave 1: LS_ADA expert weights start at 1/5
     mr1[l] = 0.0; mr2[l] = 0.0; mr3[l] = 0.0;
     if (l >= 16 && l < 20) { mr2[l] = p.vmu[l - 16]; mr3[l] = sum_powtab[l - 16]; }
@@ -434,7 +434,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   const int ro1 = (int)(L.ring[1] - L.ring[0]), ro2 = (int)(L.ring[2] - L.ring[1]), ro3 = (int)(L.ring[3] - L.ring[2]);
   const int rofs[4] = {0, ro1, ro1 + ro2, ro1 + ro2 + ro3};                                                    // search sweep: ring s = ring[0] + rofs[s] (one LDS base)
   // uniform mixer state (wave 0)
-  double smrs[2] = {0.0, 0.0}, S0 = 0.0, S1 = 0.0, denom = 0.0, inv_alpha = 0.0, phi = 0.0;   // wave 3 / wave 2 uniform state
+  // Wave-uniform state of the mixer chain that lives from one sample to the next -- ALC's S0, S1, the RLS phi / denom / 1/alpha (wave 2),
+  // BlendExp's two loss EMAs (wave 3): seven doubles every lane of every wave held in registers although one wave uses each.  Round 6: they
+  // live in LDS (the former rph array) and travel with loads / stores the waves issue anyway; the 14 registers were what spilled.
+  double *const us = L.rph;       // [0] S0 [1] S1 [2] phi [3] denom [4] 1/alpha [5] [6] smrs
   bool have_prev = false;
 
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // optional section cycle counters (debug)
@@ -697,7 +700,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
 #pragma unroll
             for (int j = 0; j < M; j++) pr[j] = prow[j];
             if (have_prev) {            // P update of row l (rls.cpp:47-56) of the PREVIOUS step, deferred to here where it hides under wave 0's head
-              const double phl = ph_r[g];
+              const double phl = ph_r[g], denom = us[3], inv_alpha = us[4];
 #pragma unroll
               for (int j = 0; j < M; j++) { pr[j] = fma(-denom, phl * phu[j], pr[j]) * inv_alpha; prow[j] = pr[j]; }
             }
@@ -709,17 +712,17 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           double p2[M];
 #pragma unroll
           for (int j = 0; j < M; j++) p2[j] = ex.lane_bcast(ph_r, 128 + j);
-          phi = fmax(dot_canon_n<M>([&](int j) { return xu[j]; }, [&](int j) { return p2[j]; }), 1e-8);
+          const double phi = fmax(dot_canon_n<M>([&](int j) { return xu[j]; }, [&](int j) { return p2[j]; }), 1e-8);
+          if (ex.is_lane0w()) us[2] = phi;
         });
       });
       // Wave 0 (round 6): every LDS input of the head -- last step's blend weights, RLS prediction and expert weights, the constants, this
       // sample's p_lpc and value -- is requested HERE, together with the stage totals' loads: one LDS round trip for the whole head where
       // the compiler's placement (loads next to their first use, under register pressure) had eight in a row.
-      double h_smw0 = 0.0, h_smw1 = 0.0, h_rpx = 0.0, h_pa = 0.0, h_pa1 = 0.0, h_lo = 0.0, h_hi = 0.0, h_plpc = 0.0;
+      double h_smw0 = 0.0, h_smw1 = 0.0, h_rpx = 0.0, h_plpc = 0.0;
       int h_sv = 0;
       ex.wave(0, [&]() {
         h_smw0 = L.hs[12]; h_smw1 = L.hs[13]; h_rpx = L.hs[10];
-        h_pa = L.cst[8]; h_pa1 = L.cst[9]; h_lo = L.cst[14]; h_hi = L.cst[15];
         if (!dec) { h_plpc = L.pin[tt]; h_sv = L.sv[tt]; }
       });
       ex.wave_par(0, [&](int l) {
@@ -802,7 +805,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       bool dec_ok = true;
       ex.wave(0, [&]() {
         const double smw0 = h_smw0, smw1 = h_smw1;
-        const double pa = h_pa, pa1 = h_pa1, lo = h_lo, hi = h_hi;        // proj_alpha, 1 - proj_alpha, Cascade clamp range
+        const double pa = L.cst[8], pa1 = L.cst[9], lo = L.cst[14], hi = L.cst[15];        // proj_alpha, 1 - proj_alpha, Cascade clamp range (with the expert weights: one batch)
         // Cascade::Predict (cascade.h:93-100)
         const double rpx = h_rpx;                          // dot(rx, rw), left in hs[10] by wave 2 after its update
         double pl[5], ep[2], exw[10];      // (the ten expert weights are loaded here, not with the early batch: 20 registers live across the totals cost more in spills than the round trip saves)
@@ -868,20 +871,24 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       });
       // ---- wave 2: RLS::Update + ALC (rls.cpp:28-56, rls.h:21-39) except the P update (deferred);
       // ph = P x and phi were computed before the barrier (they do not depend on this step's prediction)
-      double rerr = 0.0, alpha = 0.0, rbp4 = 0.0;
+      double rerr = 0.0, alpha = 0.0, rbp4 = 0.0, phi = 0.0, denom = 0.0;
       ex.wave(2, [&]() {
         rbp4 = L.hs[8];
-        rerr = rbp4 - L.hs[9];
+        const double rpx_ = L.hs[9], lm_alpha = L.cst[13], S0 = us[0], S1 = us[1];
+        phi = us[2];
+        SA_SCHED_FENCE();                    // the six loads leave together (the shape parameter used to be fetched after the division: one more LDS round trip in the chain)
+        rerr = rbp4 - rpx_;
         const double err2 = rerr * rerr;
         const double R = fmax(S0 - S1, 1e-5);
         const double nis = err2 / (phi + R);
-        const double mm = sa_exp_t(-L.cst[13] * nis, exptab);
+        const double mm = sa_exp_t(-lm_alpha * nis, exptab);
         alpha = fma(0.999 - 0.99, mm, 0.99);
-        S0 = fma(0.95, S0, (1.0 - 0.95) * err2);
-        S1 = fma(0.95, S1, (1.0 - 0.95) * phi);
+        if (ex.is_lane0w()) { us[0] = fma(0.95, S0, (1.0 - 0.95) * err2); us[1] = fma(0.95, S1, (1.0 - 0.95) * phi); }
       });
-      ex.wave_par(2, [&](int g) { if ((g & 63) < 2) rcp_r[g] = 1.0 / ((g & 63) == 0 ? alpha + phi : alpha); });   // both reciprocals in one instruction stream
-      ex.wave(2, [&]() { denom = ex.lane_bcast(rcp_r, 128); inv_alpha = ex.lane_bcast(rcp_r, 129); });
+      ex.wave_par(2, [&](int g) {            // both reciprocals in one instruction stream: lane 0 denom = 1 / (alpha + phi), lane 1 1 / alpha (for the next step's P update)
+        if ((g & 63) < 2) { rcp_r[g] = 1.0 / ((g & 63) == 0 ? alpha + phi : alpha); us[3 + (g & 63)] = rcp_r[g]; }
+      });
+      ex.wave(2, [&]() { denom = ex.lane_bcast(rcp_r, 128); });
       ex.wave_par(2, [&](int g) { if ((g & 63) < m) rw_r[g] = fma(rerr, denom * ph_r[g], rw_r[g]); });
       ex.wave_shift_up1(2, x_r);                                                              // RollBack(x, val), rls.cpp:64: x[l] <- x[l-1] ...
       ex.wave_par(2, [&](int g) { if ((g & 63) == 0) x_r[g] = rbp4; });                       // ... and x[0] <- val (the RLS stage's target bp[4])
@@ -898,10 +905,13 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       // ---- wave 3: BlendExp<RunSumEMA>::Update (blend.h:31-90)
       double zm[2] = {0, 0}, maxz = 0.0;
       ex.wave(3, [&]() {
+        const double tg_ = L.hs[0], e0_ = L.hs[1], e1_ = L.hs[2], sm0 = us[5], sm1 = us[6];
+        SA_SCHED_FENCE();
         for (int e = 0; e < 2; e++) {
-          const double loss = fabs(L.hs[0] - L.hs[1 + e]);
-          smrs[e] = fma(0.95, smrs[e], (1.0 - 0.95) * (-loss));
-          zm[e] = 1.0 * smrs[e];
+          const double loss = fabs(tg_ - (e ? e1_ : e0_));
+          const double sm = fma(0.95, e ? sm1 : sm0, (1.0 - 0.95) * (-loss));
+          if (ex.is_lane0w()) us[5 + e] = sm;
+          zm[e] = 1.0 * sm;
         }
         maxz = fmax(zm[0], zm[1]);
       });
