@@ -143,9 +143,12 @@ static void launch_ols_c(hipStream_t s, const WorkItem *d_items, const int *d_id
 // 33..64 taps on one wave, matrix 2D-cyclic over the lanes (pred_ols_grid.h): NB = blocks of 8 rows / columns.  158 / 188 / 219 / 256
 // registers for NB = 5 .. 8 (the backward solve keeps its operands sixteen to a register, DPP row broadcast): three waves per SIMD for
 // the 40-tap instance, two for the others; search and final pass run the same build.
-template <int NB> constexpr int grid_waves() { return NB <= 5 ? 3 : 2; }
-template <int NB>
-__global__ __launch_bounds__(64, (grid_waves<NB>())) void k_ols_grid(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
+// Round 6: the 64-tap instance needs 260 registers; at two waves per SIMD (256) the four missing ones were two solved weights of the
+// backward substitution, stored to and reloaded from scratch inside that dependent chain (31 scratch instructions).  The final pass
+// (LAT: k = 1, one factorisation per sample, a few items per SIMD at most) therefore runs it at one wave per SIMD, where it has them.
+template <int NB, bool LAT> constexpr int grid_waves() { return NB <= 5 ? 3 : (NB == 8 && LAT ? 1 : 2); }
+template <int NB, bool LAT = false>
+__global__ __launch_bounds__(64, (grid_waves<NB, LAT>())) void k_ols_grid(const WorkItem *items, const int *idx, PcmView v, double *pbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (idx[blockIdx.x] < 0) return;                 // padding entry of the XCD-interleaved launch list
   const WorkItem &it = items[idx[blockIdx.x]];
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(64, (grid_waves<NB>())) void k_ols_grid(const WorkI
   double *out = (it.pin_kept ? v.keep : pbuf) + it.off_pin;
   ols_stage_grid<ExecDev<64>, NB>(ex, p, self, other, it.n, out, smem, v.prof);
 }
-template <int NB>
+template <int NB, bool LAT = false>
 static void launch_ols_grid_c(hipStream_t s, const WorkItem *d_items, const int *d_idx, int count, PcmView v, double *d_p) {
   const size_t bytes = OlsLdsGrid::bytes(8 * NB);       // <= 24 KB: below the default dynamic-LDS limit
-  hipLaunchKernelGGL((k_ols_grid<NB>), dim3(count), dim3(64), bytes, s, d_items, d_idx, v, d_p);
+  hipLaunchKernelGGL((k_ols_grid<NB, LAT>), dim3(count), dim3(64), bytes, s, d_items, d_idx, v, d_p);
 }
 
 constexpr int kOlsPanelThreads = 256;   // panel width 4 (8 waves measured slower: one workgroup per CU, and a barrier-parked wave sharing the SIMD of wave 0 doubles the time of its serial solve)
@@ -186,7 +189,7 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
       case 3: launch_ols_grid_c<5>(s, d_items, d_idx, count, v, d_p); break;
       case 4: launch_ols_grid_c<6>(s, d_items, d_idx, count, v, d_p); break;
       case 5: launch_ols_grid_c<7>(s, d_items, d_idx, count, v, d_p); break;
-      default: launch_ols_grid_c<8>(s, d_items, d_idx, count, v, d_p); break;
+      default: if (latency_bound) launch_ols_grid_c<8, true>(s, d_items, d_idx, count, v, d_p); else launch_ols_grid_c<8>(s, d_items, d_idx, count, v, d_p); break;
     }
     return;
   }
@@ -249,7 +252,7 @@ template <> struct LmsCfg<0> { static constexpr int ROUNDS = 1; using C = LmsA; 
 #define SACAMD_EXP_LMS134_MINB 2
 #endif
 #ifndef SACAMD_EXP_LMS56_MINB
-#define SACAMD_EXP_LMS56_MINB 2
+#define SACAMD_EXP_LMS56_MINB 3        // round 6: factored step-size table (pred_lms.h) -> 166 registers, 64-sample staging -> 52.4 KB of LDS: three per CU
 #endif
 template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
 template <> struct LmsCfg<2> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 512, MINB = 1; };

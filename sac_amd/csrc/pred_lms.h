@@ -47,8 +47,20 @@ constexpr int kRlsMax = 10;
 #endif
 // search sweep: slots whose history loads are in flight ahead of the arithmetic (4 registers per slot); the 30-slot layouts
 // already fill the 256-VGPR budget with their tap state
-template <class C> constexpr int lms_ahead() { return C::total > 22 ? 2 : SACAMD_EXP_LMS_AHEAD; }
+template <class C> constexpr int lms_ahead() { return C::total >= 22 ? 2 : SACAMD_EXP_LMS_AHEAD; }
 
+// Factored step-size table (round 6).  mutab[i] = mu_decay^i (ls.h:40) is one of the three doubles a tap keeps in registers.  With tap
+// i = NL j + l it factors into a per-lane value ml[l] = mutab[l] (one register per STAGE) and a per-slot value Mj = mutab[NL j] (uniform,
+// read from LDS with the slot's history): the update becomes  w = fma(Mj, (wg ml) xo, w)  instead of  fma(mutab[i], wg xo, w) -- the same
+// number of operations, two registers per tap less (22-slot layouts: 211 -> 166 registers = three workgroups per CU).  Mj ml differs from
+// the table's correctly rounded mu_decay^i by ~1 ulp (exactly equal when mu_decay = 1, the default): a perturbation of the update far below
+// the weight's own rounding, the same class as the free summation order of these search evaluations -- the final pass keeps the
+// table.  Taps beyond the stage length need no zero entry any more: the history behind the window is KEPT at zero (the gains lane clears
+// the value that leaves the window at every push), so their update term is 0 and their weight stays +0.  SACAMD_EXP_LMS_MTFAC=0: table.
+#ifndef SACAMD_EXP_LMS_MTFAC
+#define SACAMD_EXP_LMS_MTFAC 1
+#endif
+constexpr bool kLmsMtFac = SACAMD_EXP_LMS_MTFAC != 0;
 template <int N> struct DArr { double v[N]; };
 
 // f(std::integral_constant<int, I>{}) for I = 0 .. N-1: a loop whose index is a compile-time constant in every
@@ -139,6 +151,7 @@ struct LmsLds {
   double *part;     // [2][NL/64][8]
   double *bc;       // [4]: wgrad of each stage
   double *pin, *pout;
+  double *mjt;               // search layouts with the factored step-size table: Mj of every slot [C::total]
   double *rx, *rw, *rph;     // RLS history / weights mirror / P*x
   double *P;                 // RLS inverse covariance, row l at P + l * kRlsMax (owned by the lanes of wave 2)
   double *pv;                // stage predictions p[0..3]
@@ -151,6 +164,9 @@ struct LmsLds {
   int *sv;
   // ringcap[s] >= vn[s] + 1 of every work-item of the launch (<= C::slots(s) * NL + 1): the LDS
   // footprint follows the taps actually in use, not the register-capacity class
+  // samples staged per global <-> LDS exchange (p_lpc in, p_lpc + p_lms out, the channel's samples): one per lane, except in the 22-slot
+  // search layouts, where 64 keep the workgroup under a third of a CU's LDS (three workgroups per CU)
+  SA_HD static constexpr int chunk() { return (CANON == 0 && C::total == 22 && NL == 256) ? 64 : NL; }
   // search layouts (CANON 0, round 6): the sweep visits every slot of the layout, so every ring has the layout's capacity
   SA_HD static constexpr int cap_of(int s, int c) { return CANON ? c : C::slots(s) * NL + 1; }
   SA_HD static size_t bytes(const int *ringcap) {
@@ -159,8 +175,10 @@ struct LmsLds {
     for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringlen(cap_of(s, ringcap[s]))) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
     if (CANON) d += 64 + 32 + 64 + 32;
     if (CANON == 3) d += (size_t)(NL / 2) * C::c0;     // mutab of the dot lanes, lane-major per wave
+    if (CANON == 0 && kLmsMtFac) d += C::total;
+    d -= 2 * (NL - chunk());                           // pin / pout hold one chunk
     d += 2 * (NL / 64) * 8 + 4 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 4 + 10 + 16 + 16 + kLibmLdsDoubles;   // part, bc[4], pin/pout, RLS, pv[4], exwm, cst, hs, libm   // pin/pout: NL samples staged per exchange
-    return d * sizeof(double) + NL * sizeof(int) + 16;
+    return d * sizeof(double) + chunk() * sizeof(int) + 16;
   }
   SA_HD static size_t bytes() {
     const int full[4] = {C::slots(0) * NL + 1, C::slots(1) * NL + 1, C::slots(2) * NL + 1, C::slots(3) * NL + 1};
@@ -181,7 +199,8 @@ struct LmsLds {
     if (CANON == 3) { mt[0] = d; d += (size_t)(NL / 2) * C::c0; }
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 4;
-    pin = d; d += NL; pout = d; d += NL;
+    pin = d; d += chunk(); pout = d; d += chunk();
+    mjt = d; if (CANON == 0 && kLmsMtFac) d += C::total;
     rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
     P = d; d += kRlsMax * kRlsMax;
     pv = d; d += 4; exwm = d; d += 10; cst = d; d += 16; hs = d; d += 16;
@@ -253,10 +272,10 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
 // The four stages' slots form ONE pipeline (flat slot q = C::first(s) + j): the loads of the next stage's first slots are in flight
 // under the last slots of the stage before, so a sample exposes one LDS round trip, not four.
 template <class C> SA_HD constexpr int lms_flat_stage(int q) { return q < C::first(1) ? 0 : (q < C::first(2) ? 1 : (q < C::first(3) ? 2 : 3)); }
-template <int NL, class C, int AHEAD, class T, class A8>
-SA_HD void lms_sweep(T &Wl, const T &MTl, const T &PTl, A8 &accl, const double *ring0, const int *rofs, const int *pos, const double *bc, int l) {
+template <int NL, class C, int AHEAD, class T, class TM, class A8>
+SA_HD void lms_sweep(T &Wl, const TM &MTl, const T &PTl, A8 &accl, const double *ring0, const int *rofs, const int *pos, const double *bc, const double *mjt, int l) {
   constexpr int TOT = C::total, G = AHEAD < TOT ? AHEAD : TOT;
-  double bn[G], bo[G];
+  double bn[G], bo[G], bm[kLmsMtFac ? G : 1];
   const double *a0[4], *a1[4];
   int thr[4];
   double wg[4];
@@ -267,9 +286,11 @@ SA_HD void lms_sweep(T &Wl, const T &MTl, const T &PTl, A8 &accl, const double *
       const int u = pos[s] + l;
       a0[s] = ring0 + rofs[s] + u; a1[s] = a0[s] - cp; thr[s] = cp - u;      // slot j wraps iff NL j >= thr
       wg[s] = bc[s];
+      if constexpr (kLmsMtFac) wg[s] = wg[s] * MTl.v[s];     // (wg ml): the lane's factor of the step sizes, once per stage
     }
     const double *a = (j * NL >= thr[s]) ? a1[s] : a0[s];
     bn[q % G] = a[j * NL]; bo[q % G] = a[j * NL + 1];
+    if constexpr (kLmsMtFac) bm[q % G] = mjt[q];            // the slot's factor (uniform address: one broadcast read)
   };
   static_for<0, G>(load);
   double d = 0.0, sp = 0.0;
@@ -277,8 +298,10 @@ SA_HD void lms_sweep(T &Wl, const T &MTl, const T &PTl, A8 &accl, const double *
     constexpr int q = decltype(QC)::value, s = lms_flat_stage<C>(q), j = q - C::first(s);
     if constexpr (j == 0) { d = 0.0; sp = 0.0; }
     const double xn = bn[q % G], xo = bo[q % G];
+    double mq;
+    if constexpr (kLmsMtFac) mq = bm[q % G]; else mq = MTl.v[q];
     if constexpr (q + G < TOT) load(std::integral_constant<int, q + G>{});
-    double w = fma(MTl.v[q], wg[s] * xo, Wl.v[q]);
+    double w = fma(mq, wg[s] * xo, Wl.v[q]);
     w = clampd(w, -10.0, 10.0);
     Wl.v[q] = w;
     d = fma(xn, w, d);
@@ -295,7 +318,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
                      unsigned long long *prof = nullptr, const DecLink *dec = nullptr, const double *tabc = nullptr) {
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
-  constexpr int kLmsChunk = NL;   // samples staged per global<->LDS exchange: one element per lane
+  constexpr int kLmsChunk = LmsLds<NL, C, CANON>::chunk();   // samples staged per global<->LDS exchange
   LmsLds<NL, C, CANON> L;
   L.carve(lds_base, ringcap);
   auto ridx = [](int a) { return LmsLds<NL, C, CANON>::ridx(a); };
@@ -312,7 +335,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   static_assert(!CANON || (C::c0 >= C::c1 && C::c0 >= C::c2 && C::c0 >= C::c3), "stage 0 holds the most slots");
 
   typename E::template Reg<DArr<C::total * RD>> W;                // CANON: slot (stage s, round r, j) at C::first(s) * RD + r * J + j
-  typename E::template Reg<DArr<CANON ? 1 : C::total>> MT, PT;   // CANON: the tables stay in LDS (read once per sample): the chain operands need the registers
+  typename E::template Reg<DArr<CANON ? 1 : (kLmsMtFac ? 4 : C::total)>> MT;   // search: mutab per tap, or (factored) ml of the lane per stage
+  typename E::template Reg<DArr<CANON ? 1 : C::total>> PT;       // CANON: the tables stay in LDS (read once per sample): the chain operands need the registers
   typename E::template Reg<DArr<NX>> PR;                 // CANON: powtab of this lane's power-chain taps, loaded for the duration of the chains
   typename E::template Reg<DArr<8>> acc;
   typename E::template Reg<DArr<(CANON && !LM) ? 4 : 1>> Wt;        // CANON: the chain's tail tap (taps beyond 8*floor(n/8)) of lanes m == 0
@@ -351,8 +375,12 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           const int tap = j * NL + l;
           const bool on = tap < ns[s];
           W[l].v[f + j] = 0.0;
-          MT[l].v[f + j] = on ? tp[tap] : 0.0;
+          if constexpr (!kLmsMtFac) MT[l].v[f + j] = on ? tp[tap] : 0.0;
           PT[l].v[f + j] = on ? tp[ns[s] + tap] : 0.0;
+        }
+        if constexpr (kLmsMtFac) {          // ml = mutab[l], Mj = mutab[NL j] (exact table entries; beyond the stage length: unused, 0)
+          MT[l].v[s] = l < ns[s] ? tp[l] : 0.0;
+          if (l < C::slots(s)) L.mjt[f + l] = l * NL < ns[s] ? tp[l * NL] : 0.0;
         }
       } else if constexpr (LM) {
         if (l < 8) { const int K4 = ns[s] >= 8 ? ns[s] >> 2 : 0; const int ti = 4 * K4 + l; L.tailpw[s * 8 + l] = ti < ns[s] ? tp[ns[s] + ti] : 0.0; }
@@ -447,8 +475,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   for (int t0 = 0; t0 < n; t0 += kLmsChunk) {
     // ---- stage a chunk of p_lpc / target in, flush the previous chunk of p_lpc+p_lms out
     if (!dec) ex.par([&](int l) {      // (decoder: inputs arrive and outputs leave sample by sample, see the head below)
-      if (t0 > 0) pout_g[t0 - kLmsChunk + l] = L.pout[l];
-      if (t0 + l < n) { L.pin[l] = pin_g[t0 + l]; L.sv[l] = self[t0 + l]; }
+      if (l < kLmsChunk) {
+        if (t0 > 0) pout_g[t0 - kLmsChunk + l] = L.pout[l];
+        if (t0 + l < n) { L.pin[l] = pin_g[t0 + l]; L.sv[l] = self[t0 + l]; }
+      }
     });
     ex.sync();
     const int tend = (n - t0 < kLmsChunk) ? n - t0 : kLmsChunk;
@@ -456,7 +486,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       const int par = tt & 1;
       // ---- A: fused sweep (update of previous step, predict of this step)
       if constexpr (!CANON) {
-      ex.par([&](int l) { lms_sweep<NL, C, lms_ahead<C>()>(W[l], MT[l], PT[l], acc[l], L.ring[0], rofs, pos, L.bc, l); });
+      ex.par([&](int l) { lms_sweep<NL, C, lms_ahead<C>()>(W[l], MT[l], PT[l], acc[l], L.ring[0], rofs, pos, L.bc, L.mjt, l); });
       SA_TICK(0);
       ex.wave_sum8x(acc);
       SA_TICK(1);
@@ -935,6 +965,16 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           int np = ps - 1; if (np < 0) np += cs;
           rg[ridx(np)] = bps;
           if (LM ? np < EXT3 : np == 0) rg[ridx(cs + np)] = bps;        // mirror: ring[in + 1] (lane-map layout: a lane's whole window) needs no wrap in the sweep
+          if constexpr (!CANON && kLmsMtFac) {
+            // factored step sizes: everything behind the window stays zero -- the value that was the oldest one the update read (offset
+            // nsl from the old position = nsl + 1 from the new one) leaves the window now
+            const int nsl = sl == 0 ? ns[0] : (sl == 1 ? ns[1] : (sl == 2 ? ns[2] : ns[3]));
+            if (nsl + 1 < cs) {
+              int zi = np + nsl + 1; if (zi >= cs) zi -= cs;
+              rg[zi] = 0.0;
+              if (zi == 0) rg[cs] = 0.0;
+            }
+          }
         }
       });
       SA_TICK(4);
@@ -956,7 +996,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   // flush the last chunk
   if (!dec) ex.par([&](int l) {
     const int t0 = ((n - 1) / kLmsChunk) * kLmsChunk;
-    if (n > 0 && t0 + l < n) pout_g[t0 + l] = L.pout[l];
+    if (n > 0 && l < kLmsChunk && t0 + l < n) pout_g[t0 + l] = L.pout[l];
   });
 }
 

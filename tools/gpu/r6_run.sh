@@ -46,6 +46,18 @@ PY
     for t in 1280,256,32,4 3383,1168,614,273 5400,64,16,8; do timeout 200 python tests/gpu_dbg_canon.py $t 6000; done > $O/canon_latency_$2.txt 2>&1; cat $O/canon_latency_$2.txt
     timeout 900 python -m pytest tests -q -m gpu -x -k "canonical or predictor_stages or frame_records or decoder_inverts or evaluate_costs or random_profiles or warm_start" > $O/gputests_05_$2.log 2>&1; tail -3 $O/gputests_05_$2.log
     ;;
+  bench1536)
+    timeout 1500 python bench.py --frames 1536 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_1536_$2.json 2> $O/bench_1536_$2.err
+    python - <<PY
+import json
+d=json.load(open("gpurun_out/r06/bench_1536_$2.json")); print(d["value"], d["ms_per_step"], d["bps"], d["kernel_ms"]); print({k:round(v/1e3,1) for k,v in d["kernel_instances_ms"].items()})
+PY
+    ;;
+  mtfac)    # factored step-size table + 22-slot layouts at three workgroups per CU: throughput, sections, every test that runs a search
+    timeout 300 python tests/gpu_latency.py > $O/latency_sections_$2.txt 2>&1; grep -B1 "k=4" $O/latency_sections_$2.txt | cut -c1-150 | head -4
+    timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_$2.txt 2>&1; grep "16 taps" $O/throughput_lms_$2.txt | cut -c1-160
+    timeout 1800 python -m pytest tests -q -m gpu -x --durations=5 -k "frame_records or headline or evaluate_costs or random_profiles or warm_start or de_and_cma or wide or instalments or configs_3_and_4 or kept_ols or chain or smoke or framecoder_wrapper_writes or batch" > $O/gputests_06_$2.log 2>&1; tail -9 $O/gputests_06_$2.log
+    ;;
   bench768)
     timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_$2.json 2> $O/bench_768_$2.err
     tail -c 1500 $O/bench_768_$2.json
