@@ -50,8 +50,9 @@ constexpr int kRlsMax = 10;
 template <class C> constexpr int lms_ahead() { return C::total >= 22 ? 2 : SACAMD_EXP_LMS_AHEAD; }
 
 // Factored step-size table (round 6).  mutab[i] = mu_decay^i (ls.h:40) is one of the three doubles a tap keeps in registers.  With tap
-// i = NL j + l it factors into a per-lane value ml[l] = mutab[l] (one register per STAGE) and a per-slot value Mj = mutab[NL j] (uniform,
-// read from LDS with the slot's history): the update becomes  w = fma(Mj, (wg ml) xo, w)  instead of  fma(mutab[i], wg xo, w) -- the same
+// i = NL j + l it factors into a per-lane value ml[l] = mutab[l] (one register per STAGE) and a per-slot value Mj = mutab[NL j] (uniform:
+// lane q of every wave keeps the factor of flat slot q in ONE register, the sweep takes it by v_readlane -- a per-slot LDS read was tried
+// first and cost 17 cycles per slot in LDS pipe contention): the update becomes  w = fma(Mj, (wg ml) xo, w)  instead of  fma(mutab[i], wg xo, w) -- the same
 // number of operations, two registers per tap less (22-slot layouts: 211 -> 166 registers = three workgroups per CU).  Mj ml differs from
 // the table's correctly rounded mu_decay^i by ~1 ulp (exactly equal when mu_decay = 1, the default): a perturbation of the update far below
 // the weight's own rounding, the same class as the free summation order of these search evaluations -- the final pass keeps the
@@ -151,7 +152,6 @@ struct LmsLds {
   double *part;     // [2][NL/64][8]
   double *bc;       // [4]: wgrad of each stage
   double *pin, *pout;
-  double *mjt;               // search layouts with the factored step-size table: Mj of every slot [C::total]
   double *rx, *rw, *rph;     // RLS history / weights mirror / P*x
   double *P;                 // RLS inverse covariance, row l at P + l * kRlsMax (owned by the lanes of wave 2)
   double *pv;                // stage predictions p[0..3]
@@ -175,7 +175,6 @@ struct LmsLds {
     for (int s = 0; s < 4; s++) d += ((size_t)ridx(ringlen(cap_of(s, ringcap[s]))) + 1) * (CANON == 1 ? 3 : 1);      // + the mirror element ring[cap] == ring[0]; CANON 1: + mutab, powtab
     if (CANON) d += 64 + 32 + 64 + 32;
     if (CANON == 3) d += (size_t)(NL / 2) * C::c0;     // mutab of the dot lanes, lane-major per wave
-    if (CANON == 0 && kLmsMtFac) d += C::total;
     d -= 2 * (NL - chunk());                           // pin / pout hold one chunk
     d += 2 * (NL / 64) * 8 + 4 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 4 + 10 + 16 + 16 + kLibmLdsDoubles;   // part, bc[4], pin/pout, RLS, pv[4], exwm, cst, hs, libm   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + chunk() * sizeof(int) + 16;
@@ -200,7 +199,6 @@ struct LmsLds {
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 4;
     pin = d; d += chunk(); pout = d; d += chunk();
-    mjt = d; if (CANON == 0 && kLmsMtFac) d += C::total;
     rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
     P = d; d += kRlsMax * kRlsMax;
     pv = d; d += 4; exwm = d; d += 10; cst = d; d += 16; hs = d; d += 16;
@@ -272,10 +270,10 @@ SA_HD double tr_s2pow_g(int n, A x, B pw) {
 // The four stages' slots form ONE pipeline (flat slot q = C::first(s) + j): the loads of the next stage's first slots are in flight
 // under the last slots of the stage before, so a sample exposes one LDS round trip, not four.
 template <class C> SA_HD constexpr int lms_flat_stage(int q) { return q < C::first(1) ? 0 : (q < C::first(2) ? 1 : (q < C::first(3) ? 2 : 3)); }
-template <int NL, class C, int AHEAD, class T, class TM, class A8>
-SA_HD void lms_sweep(T &Wl, const TM &MTl, const T &PTl, A8 &accl, const double *ring0, const int *rofs, const int *pos, const double *bc, const double *mjt, int l) {
+template <int NL, class C, int AHEAD, class E, class T, class TM, class A8, class RM>
+SA_HD void lms_sweep(E &ex, T &Wl, const TM &MTl, const T &PTl, A8 &accl, const double *ring0, const int *rofs, const int *pos, const double *bc, const RM &mjv, int l) {
   constexpr int TOT = C::total, G = AHEAD < TOT ? AHEAD : TOT;
-  double bn[G], bo[G], bm[kLmsMtFac ? G : 1];
+  double bn[G], bo[G];
   const double *a0[4], *a1[4];
   int thr[4];
   double wg[4];
@@ -290,7 +288,6 @@ SA_HD void lms_sweep(T &Wl, const TM &MTl, const T &PTl, A8 &accl, const double 
     }
     const double *a = (j * NL >= thr[s]) ? a1[s] : a0[s];
     bn[q % G] = a[j * NL]; bo[q % G] = a[j * NL + 1];
-    if constexpr (kLmsMtFac) bm[q % G] = mjt[q];            // the slot's factor (uniform address: one broadcast read)
   };
   static_for<0, G>(load);
   double d = 0.0, sp = 0.0;
@@ -299,7 +296,7 @@ SA_HD void lms_sweep(T &Wl, const TM &MTl, const T &PTl, A8 &accl, const double 
     if constexpr (j == 0) { d = 0.0; sp = 0.0; }
     const double xn = bn[q % G], xo = bo[q % G];
     double mq;
-    if constexpr (kLmsMtFac) mq = bm[q % G]; else mq = MTl.v[q];
+    if constexpr (kLmsMtFac) mq = ex.wave_lane(mjv, l, q); else mq = MTl.v[q];     // the slot's factor: lane q of every wave holds it (v_readlane -> a scalar operand of the fma)
     if constexpr (q + G < TOT) load(std::integral_constant<int, q + G>{});
     double w = fma(mq, wg[s] * xo, Wl.v[q]);
     w = clampd(w, -10.0, 10.0);
@@ -336,6 +333,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
 
   typename E::template Reg<DArr<C::total * RD>> W;                // CANON: slot (stage s, round r, j) at C::first(s) * RD + r * J + j
   typename E::template Reg<DArr<CANON ? 1 : (kLmsMtFac ? 4 : C::total)>> MT;   // search: mutab per tap, or (factored) ml of the lane per stage
+  typename E::template Reg<double> mjv;                          // search, factored table: lane q of every wave holds Mj of flat slot q
   typename E::template Reg<DArr<CANON ? 1 : C::total>> PT;       // CANON: the tables stay in LDS (read once per sample): the chain operands need the registers
   typename E::template Reg<DArr<NX>> PR;                 // CANON: powtab of this lane's power-chain taps, loaded for the duration of the chains
   typename E::template Reg<DArr<8>> acc;
@@ -367,6 +365,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   auto &exz_r = mr0;                                                        // wave 3
   ex.par([&](int l) {
     const double *tp = tab;
+    mjv[l] = 0.0;
     #pragma unroll
     for (int s = 0; s < 4; s++) {
       const int f = C::first(s);
@@ -380,7 +379,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         }
         if constexpr (kLmsMtFac) {          // ml = mutab[l], Mj = mutab[NL j] (exact table entries; beyond the stage length: unused, 0)
           MT[l].v[s] = l < ns[s] ? tp[l] : 0.0;
-          if (l < C::slots(s)) L.mjt[f + l] = l * NL < ns[s] ? tp[l * NL] : 0.0;
+          const int jq = (l & 63) - f;       // lane q = f + j of every wave: the factor of flat slot q
+          if (jq >= 0 && jq < C::slots(s)) mjv[l] = jq * NL < ns[s] ? tp[jq * NL] : 0.0;
         }
       } else if constexpr (LM) {
         if (l < 8) { const int K4 = ns[s] >= 8 ? ns[s] >> 2 : 0; const int ti = 4 * K4 + l; L.tailpw[s * 8 + l] = ti < ns[s] ? tp[ns[s] + ti] : 0.0; }
@@ -486,7 +486,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
       const int par = tt & 1;
       // ---- A: fused sweep (update of previous step, predict of this step)
       if constexpr (!CANON) {
-      ex.par([&](int l) { lms_sweep<NL, C, lms_ahead<C>()>(W[l], MT[l], PT[l], acc[l], L.ring[0], rofs, pos, L.bc, L.mjt, l); });
+      ex.par([&](int l) { lms_sweep<NL, C, lms_ahead<C>()>(ex, W[l], MT[l], PT[l], acc[l], L.ring[0], rofs, pos, L.bc, mjv, l); });
       SA_TICK(0);
       ex.wave_sum8x(acc);
       SA_TICK(1);
@@ -971,8 +971,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
             const int nsl = sl == 0 ? ns[0] : (sl == 1 ? ns[1] : (sl == 2 ? ns[2] : ns[3]));
             if (nsl + 1 < cs) {
               int zi = np + nsl + 1; if (zi >= cs) zi -= cs;
-              rg[zi] = 0.0;
-              if (zi == 0) rg[cs] = 0.0;
+              double zero = 0.0;
+              SA_PIN_F64(zero);              // materialised here (hoisted out of the sample loop the constant was spilled to scratch and reloaded per sample)
+              rg[zi] = zero;
+              if (zi == 0) rg[cs] = zero;
             }
           }
         }
