@@ -61,7 +61,9 @@ template <class C> constexpr int lms_ahead() { return C::total >= 22 ? 2 : SACAM
 #ifndef SACAMD_EXP_LMS_MTFAC
 #define SACAMD_EXP_LMS_MTFAC 1
 #endif
-constexpr bool kLmsMtFac = SACAMD_EXP_LMS_MTFAC != 0;
+// Only where it buys residency: the 22-slot layouts (three workgroups per CU instead of two: +18 % saturated throughput).  The 15- and
+// 30-slot layouts keep the table in registers -- factored they ran 5-6 % slower (two v_readlane per slot) at unchanged residency.
+template <class C> SA_HD constexpr bool lms_mtfac() { return SACAMD_EXP_LMS_MTFAC != 0 && C::total == 22; }
 template <int N> struct DArr { double v[N]; };
 
 // f(std::integral_constant<int, I>{}) for I = 0 .. N-1: a loop whose index is a compile-time constant in every
@@ -273,6 +275,7 @@ template <class C> SA_HD constexpr int lms_flat_stage(int q) { return q < C::fir
 template <int NL, class C, int AHEAD, class E, class T, class TM, class A8, class RM>
 SA_HD void lms_sweep(E &ex, T &Wl, const TM &MTl, const T &PTl, A8 &accl, const double *ring0, const int *rofs, const int *pos, const double *bc, const RM &mjv, int l) {
   constexpr int TOT = C::total, G = AHEAD < TOT ? AHEAD : TOT;
+  constexpr bool kLmsMtFac = lms_mtfac<C>();
   double bn[G], bo[G];
   const double *a0[4], *a1[4];
   int thr[4];
@@ -316,6 +319,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
   constexpr int NL = E::nl;
   constexpr int NW = NL / 64;
   constexpr int kLmsChunk = LmsLds<NL, C, CANON>::chunk();   // samples staged per global<->LDS exchange
+  constexpr bool kLmsMtFac = lms_mtfac<C>();      // search layouts: factored step-size table (see above)
   LmsLds<NL, C, CANON> L;
   L.carve(lds_base, ringcap);
   auto ridx = [](int a) { return LmsLds<NL, C, CANON>::ridx(a); };
