@@ -788,12 +788,22 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
             // branches; the power sum likewise afterwards (the two halves share their registers).  rmax8 / rmax4: the
             // longest tail of any stage (uniform), so that short tails load nothing they do not need.
             a = 0.0; b = 0.0;
+            // Round 6: ALL operands of the two tails are requested first -- chain sums, the (up to seven) tail taps' history and weights,
+            // the power-sum chains and powtab entries: 33 loads, one LDS round trip -- and the arithmetic follows behind a scheduling
+            // fence.  Interleaved by the compiler (a load next to each use, conditional on the tail length) this section took 3 500
+            // cycles per sample, a third of the final-pass cascade's sample time (probe build SACAMD_EXP_TICK_TOTALS).  The loads
+            // are unconditional: a tap index is clamped to the stage's last tap and the tail-weight slots are always written, so
+            // the unused operands are finite and the selects below discard them.  The power sum's tail taps 4 K4 .. n-1 are the
+            // dot tail's taps 8 K8 .. n-1 from offset 4 K4 - 8 K8 (0 or 4) on: no second set of history loads.
+            double q[8], r[4], xt[7], wt[7], pt[7];
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[u] = L.csum[(par * 4 + s) * 8 + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = L.psum[(par * 4 + s) * 4 + u];
+#pragma unroll
+            for (int u = 0; u < 7; u++) { xt[u] = hist(8 * K8 + u); wt[u] = tw[u]; pt[u] = tpw[u]; }
+            SA_SCHED_FENCE();
             {
-              double q[8], xt[7], wt[7];
-#pragma unroll
-              for (int u = 0; u < 8; u++) q[u] = L.csum[(par * 4 + s) * 8 + u];
-#pragma unroll
-              for (int u = 0; u < 7; u++) { xt[u] = 0.0; wt[u] = 0.0; if (u < rmax8) { xt[u] = hist(8 * K8 + u); wt[u] = tw[u]; } }
               if (K8 > 0) {
                 const double q0 = q[0] + q[4], q1 = q[1] + q[5], q2 = q[2] + q[6], q3 = q[3] + q[7];
                 a = ((q0 + q1) + q2) + q3;
@@ -812,11 +822,10 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
               a = a + init;
             }
             {
-              double r[4], xp[7], pt[7];
+              const bool o4 = 4 * K4 != 8 * K8;        // the power tail starts four taps into the dot tail (then it has at most three terms)
+              double xp[7];
 #pragma unroll
-              for (int u = 0; u < 4; u++) r[u] = L.psum[(par * 4 + s) * 4 + u];
-#pragma unroll
-              for (int u = 0; u < 7; u++) { xp[u] = 0.0; pt[u] = 0.0; if (u < rmax4) { xp[u] = hist(4 * K4 + u); pt[u] = tpw[u]; } }
+              for (int u = 0; u < 7; u++) xp[u] = (o4 && u < 3) ? xt[u + 4] : xt[u];
               if (K8 > 0) b = ((r[0] + r[1]) + r[2]) + r[3];
               const bool g4 = r4 >= 4;
               const double v1 = fma(xp[1] * xp[1], pt[1], (xp[0] * xp[0]) * pt[0]), v2 = fma(xp[3] * xp[3], pt[3], (xp[2] * xp[2]) * pt[2]);
@@ -835,6 +844,9 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           dots_r[l] = a; spow_r[l] = b;      // (the head takes the stage predictions from these lanes by v_readlane: no LDS hand-over)
         }
       });
+#if defined(SACAMD_EXP_TICK_TOTALS)
+      SA_TICK(7);                            // build-time probe: section 7 ("bar2" column) = the stage totals, "head" = what follows them
+#endif
       double bp[5] = {0, 0, 0, 0, 0};
       bool dec_ok = true;
       ex.wave(0, [&]() {
