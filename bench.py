@@ -178,19 +178,33 @@ def gather_records(recs, rank, world, device):
     return res
 
 
-def cpu_baseline(frame, framesize, nthreads, mode="high"):
+def cpu_baseline(frame, framesize, nthreads, mode="high", maxnfunc=None, threads_only=False):
     """Reference `--high --opt-cfg=dds,N --opt-reset` CPU encode of ONE frame of the benchmark's own batch
     (frame 0 of rank 0, full length, same configuration) on one host core: genuine reference objects
     (oracle/_ref) when they were built, else the oracle restatement."""
     from oracle_api import Checker, frame_cfg, ref_available
+    global _CPU_THREADS_N
 
     kind = "reference" if ref_available() else "port"
     chk = Checker("ref" if kind == "reference" else "orc")
-    cfg = frame_cfg(mode, num_threads=nthreads, reset=1)
+    cfg = frame_cfg(mode, num_threads=nthreads, reset=1, maxnfunc=maxnfunc)
+    nsamp = frame.size
+    if threads_only and kind == "reference" and nthreads > 1 and hasattr(chk.lib, "ref_set_parallel_eval"):
+        # the long presets (--veryhigh E = 300, --best): a serial run of ONE frame is minutes of CPU; time only what the reference itself
+        # does with --opt-cfg=dds,N -- the N candidates of a generation on N threads (Opt::eval_points_mt) -- and say so (cores = N)
+        chk.lib.ref_set_parallel_eval(1)
+        t = time.time()
+        r = chk.encode_frame(frame, cfg, framesize)
+        dt = time.time() - t
+        chk.lib.ref_set_parallel_eval(0)
+        _CPU_THREADS_N = None
+        return {"value": nsamp / dt / 1e6, "unit": "MSamples/s", "cores": nthreads, "kind": kind, "seconds": dt, "bps": 8 * len(r["record"]) / nsamp,
+                "sample": f"frame 0 of this run's batch ({frame.shape[1] / RATE:g} s, {nsamp} samples), --{mode} --opt-cfg=dds,{nthreads} --opt-reset"
+                          + (f" with {maxnfunc} evaluations" if maxnfunc else "") + f"; genuine reference objects (oracle/_ref, g++ -O3 -mavx2 -mfma build of the "
+                          f"container), the {nthreads} candidates of each DDS generation on {nthreads} threads as the reference runs that option (no serial run: minutes per frame)"}, r["record"]
     t = time.time()
     r = chk.encode_frame(frame, cfg, framesize)
     dt = time.time() - t
-    nsamp = frame.size
     secs = frame.shape[1] / RATE
     # the same encode with the reference's own threading for --opt-cfg=dds,N: the N candidates of a generation on N threads
     # (genuine Opt::eval_points_mt, opt/opt.cpp:11-43); only with the genuine-reference checker
@@ -203,7 +217,6 @@ def cpu_baseline(frame, framesize, nthreads, mode="high"):
         chk.lib.ref_set_parallel_eval(0)
         tn = {"value": nsamp / dtn / 1e6, "unit": "MSamples/s", "cores": nthreads, "seconds": dtn, "same_record": rn["record"] == r["record"],
               "sample": f"the same frame, the {nthreads} candidates of each DDS generation on {nthreads} threads as the reference runs --opt-cfg=dds,{nthreads}"}
-    global _CPU_THREADS_N
     _CPU_THREADS_N = tn
     return {"value": nsamp / dt / 1e6, "unit": "MSamples/s", "cores": 1, "kind": kind, "seconds": dt,
             "bps": 8 * len(r["record"]) / nsamp,
@@ -291,6 +304,8 @@ def main():
     ap.add_argument("--dds-n", type=int, default=8, help="DDS candidates per generation (--opt-cfg=dds,N)")
     ap.add_argument("--mode", default="high")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--maxnfunc", type=int, default=None, help="evaluation count of the search (default: the preset's, cmdline.cpp:127-156)")
+    ap.add_argument("--cpu-threads-only", action="store_true", help="CPU baseline: only the reference's own dds,N threading of frame 0 (long presets)")
     ap.add_argument("--verify", action="store_true", help="decode every record of the last step with the CPU checker afterwards (slow)")
     ap.add_argument("--verify-sample", type=int, default=int(os.environ.get("SAC_BENCH_VERIFY_SAMPLE", 4)),
                     help="after the timed region decode this many seeded-random frame records of the last step with the CPU reference "
@@ -394,7 +409,7 @@ def main():
     d_pcm = torch.from_numpy(il).to(device)            # interleaved L/R int16, resident in HBM
     torch.cuda.synchronize()
     t_h2d = time.perf_counter() - t_h2d
-    cfg = api.make_cfg(args.mode, num_threads=args.dds_n, reset=1)
+    cfg = api.make_cfg(args.mode, num_threads=args.dds_n, reset=1, maxnfunc=args.maxnfunc)
     # One context holds the whole batch of this rank.  (Rounds 2-3 could software-pipeline consecutive steps over several
     # contexts; measured as a loss every time -- DESIGN.md 9 -- and removed in round 4.)
     depth = 1
@@ -442,7 +457,7 @@ def main():
     # ---- CPU baseline (rank 0, N=1): one frame of this very batch, before the timed region
     cb, cb_record = None, None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cb, cb_record = cpu_baseline(frames[0], framesize, args.dds_n, args.mode)
+        cb, cb_record = cpu_baseline(frames[0], framesize, args.dds_n, args.mode, maxnfunc=args.maxnfunc, threads_only=args.cpu_threads_only)
 
     # ---- warm-up on a reduced batch
     for _ in range(args.warmup):
@@ -478,7 +493,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt * 1e3 / nsteps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.frames} frames{'/GPU' if args.scaling == 'weak' else ' in all, split over the GPUs'} x {args.seconds:g} s stereo 16-bit 44.1 kHz, --{args.mode} "
-                                   f"--opt-cfg=dds,{args.dds_n} --opt-reset, GPU bitplane coder (BASELINE configs[2])",
+                                   + (f"--opt-cfg=dds,{args.dds_n} --opt-reset" if args.dds_n > 0 else "--opt-reset (the reference's default search: OptDDS::run_single)")
+                                   + (f", {args.maxnfunc} evaluations" if args.maxnfunc else "") + ", GPU bitplane coder"
+                                   + (" (BASELINE configs[2])" if args.mode == "high" and args.dds_n == 8 and not args.maxnfunc else ""),
                        "frames_per_gpu": nloc, "total_frames": total_frames, "frame_seconds": args.seconds, "dds_n": args.dds_n,
                        "rccl_ranks": world if dist is not None else 1,
                        "record_gather": gather_kind, "record_gather_note": gather_note,
@@ -530,7 +547,7 @@ def main():
                 if cls < 3 and os.environ.get("SACAMD_OLS_PACK", "1") != "0":
                     return ("k_ols_pack<16,16>", "k_ols_pack<24,32>", "k_ols_pack<32,32>")[cls]
                 return f"k_ols<{64 if cls < 7 else 256},{OLS_NMAX[cls]}>"
-            return f"k_lms<{cls}>" + (" (canonical order, final pass)" if cls >= 7 else "")
+            return f"k_lms<{cls}>" + (" (canonical order, final pass)" if 7 <= cls <= 13 else "")      # 14, 15: the round-6 search layouts
         cands = {}
         for (kind, cls), (ms, launches, isteps, flops) in ct.items():
             cands[kname(kind, cls)] = (ms, launches, STAGE_BYTES[kind] * isteps, isteps, flops)

@@ -269,7 +269,7 @@ int sacamd_kernel_times(sacamd_ctx *ctx, double *out16, int reset);
  * k_ols_pack<16,16>; slot 1 k_ols_pack<24,32> in the search, k_ols_grid<3> in the final pass; slot 2 k_ols_grid<4>;
  * slots 3..6 k_ols_grid<5..8> (one wave, matrix 2D-cyclic over the lanes); slot 7 k_ols<256,96> (four waves); slots
  * 11..14 stay zero unless SACAMD_OLS_GRID=0 selects the retired four-wave panel kernels.  kind 1 = cascade layout classes
- * 0..15 (0..6: search layouts, 7..9 and 10..13: canonical-order layouts of the final pass).  out receives 2 * 16 * 4 = 128
+ * 0..15 (0..6 and, since round 6, 14 / 15: search layouts; 7..9 and 10..13: canonical-order layouts of the final pass).  out receives 2 * 16 * 4 = 128
  * entries; cap = capacity of out in doubles (SACAMD_ERR_ARG if smaller).  ABI version 2 (version 1 had no cap and 80 entries). */
 int sacamd_class_times(sacamd_ctx *ctx, double *out128, int cap, int reset);
 

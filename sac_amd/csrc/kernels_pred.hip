@@ -223,6 +223,12 @@ using LmsE = LmsClass<20, 4, 5, 1>;
 // default bench run), leaving ~10 % to the 30-slot layouts
 using LmsX = LmsClass<6, 10, 4, 2>;
 using LmsY = LmsClass<13, 5, 3, 1>;
+// 14 and 15 (round 6): two more 22-slot splits.  With the factored step-size table the 22-slot layouts run three workgroups per CU and
+// ~6.9 k cycles per sample, the 30-slot layouts two and ~10.9 k; of the items no other 22-slot split holds (stage lengths of 23 045
+// search items, gpurun_out/r05/search_vn_128.npy: 2 868 of them) these two take 48 %: a long stage 0 beside a long stage 2, and three
+// mid-sized late stages.
+using LmsF = LmsClass<14, 2, 4, 2>;
+using LmsG = LmsClass<9, 5, 5, 3>;
 // canonical-order layouts of the final pass (pred_lms.h, CANON): odd slot counts (bank-conflict-free strided
 // ring reads), 256 lanes; 7: (2304, 1280, 768, 256) taps in one round over the lanes, 8: twice that in two rounds,
 // 9: four times (covers the profile maximum)
@@ -232,7 +238,7 @@ using LmsL = LmsClass<17, 9, 5, 3>;
 // the tables in LDS (mode 1, 27 instead of 9 bytes per tap) only one workgroup fits a CU from ~4000 taps on and launches
 // had to be cut wherever the combined ring sizes of their items exceeded the LDS -- 56 launches serialised on four
 // streams in the 384 x 20 s run.  Measured per-step time is the same in both modes.
-constexpr int lms_canon_mode(int cls) { return cls < kLmsCanonFirst ? 0 : (cls < kLmsCanon3First ? 2 : 3); }
+constexpr int lms_canon_mode(int cls) { return (cls < kLmsCanonFirst || cls >= 14) ? 0 : (cls < kLmsCanon3First ? 2 : 3); }
 // Lane-map canonical layouts (pred_lms.h, CANON 3): LmsClass<J,0,0,0> = J chain positions per lane; 256 lanes = 2 dot + 2
 // power-sum waves, 512 lanes = 4 + 4.  An item takes the first of these its chains fit (canon3_fits); what fits none of them
 // (more than ~7.5 k taps) falls back to the systolic four-round layout 9.
@@ -260,6 +266,8 @@ template <> struct LmsCfg<3> { static constexpr int ROUNDS = 1; using C = LmsD; 
 template <> struct LmsCfg<4> { static constexpr int ROUNDS = 1; using C = LmsE; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
 template <> struct LmsCfg<5> { static constexpr int ROUNDS = 1; using C = LmsX; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS56_MINB; };
 template <> struct LmsCfg<6> { static constexpr int ROUNDS = 1; using C = LmsY; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS56_MINB; };
+template <> struct LmsCfg<14> { static constexpr int ROUNDS = 1; using C = LmsF; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS56_MINB; };
+template <> struct LmsCfg<15> { static constexpr int ROUNDS = 1; using C = LmsG; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS56_MINB; };
 template <> struct LmsCfg<7> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 1; };
 template <> struct LmsCfg<8> { using C = LmsK; static constexpr int NL = 256, MINB = 2, ROUNDS = 2; };
 template <> struct LmsCfg<9> { using C = LmsK; static constexpr int NL = 256, MINB = 1, ROUNDS = 4; };
@@ -311,6 +319,8 @@ size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
     case 11: return LmsLds<256, LmsP33, 3>::bytes(rc.c);
     case 12: return LmsLds<256, LmsP49, 3>::bytes(rc.c);
     case 13: return LmsLds<512, LmsP33, 3>::bytes(rc.c);
+    case 14: return LmsLds<256, LmsF>::bytes(rc.c);
+    case 15: return LmsLds<256, LmsG>::bytes(rc.c);
     default: return LmsLds<512, LmsB>::bytes(rc.c);
   }
 }
@@ -328,6 +338,8 @@ int lms_class_for(const int *vn, bool canon) {
   if (fits(256, LmsA::c0, LmsA::c1, LmsA::c2, LmsA::c3)) return 0;
   if (fits(256, LmsX::c0, LmsX::c1, LmsX::c2, LmsX::c3)) return 5;
   if (fits(256, LmsY::c0, LmsY::c1, LmsY::c2, LmsY::c3)) return 6;
+  if (fits(256, LmsF::c0, LmsF::c1, LmsF::c2, LmsF::c3)) return 14;
+  if (fits(256, LmsG::c0, LmsG::c1, LmsG::c2, LmsG::c3)) return 15;
   if (fits(256, LmsB::c0, LmsB::c1, LmsB::c2, LmsB::c3)) return 1;
   if (fits(256, LmsD::c0, LmsD::c1, LmsD::c2, LmsD::c3)) return 3;
   if (fits(256, LmsE::c0, LmsE::c1, LmsE::c2, LmsE::c3)) return 4;
@@ -339,7 +351,7 @@ int lms_max_wg_per_cu(int lms_class) {
   switch (lms_class) {
     case 0: return LmsCfg<0>::MINB > 2 ? LmsCfg<0>::MINB : 2;
     case 1: return LmsCfg<1>::MINB; case 3: return LmsCfg<3>::MINB; case 4: return LmsCfg<4>::MINB;
-    case 5: return LmsCfg<5>::MINB; case 6: return LmsCfg<6>::MINB;
+    case 5: return LmsCfg<5>::MINB; case 6: return LmsCfg<6>::MINB; case 14: return LmsCfg<14>::MINB; case 15: return LmsCfg<15>::MINB;
     case 10: return LmsCfg<10>::MINB;
     case 2: case 9: case 12: case 13: return 1;
     default: return 2;
@@ -363,6 +375,8 @@ void launch_lms(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
     case 11: launch_lms_c<11>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 12: launch_lms_c<12>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     case 13: launch_lms_c<13>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 14: launch_lms_c<14>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
+    case 15: launch_lms_c<15>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
     default: launch_lms_c<2>(s, d_items, d_idx, count, rc, v, d_tab, d_p, d_q); break;
   }
 }

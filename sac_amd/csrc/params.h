@@ -17,7 +17,7 @@ constexpr int kStages = 4;
 // regressor-length capacity of each OLS kernel instance; the last one is the two-wave generic path
 constexpr int kNumOlsClasses = 8;
 constexpr int kOlsClassMax[kNumOlsClasses] = {16, 24, 32, 40, 48, 56, 64, 96};
-constexpr int kNumLmsClasses = 14;   // 0..6 search layouts (free summation order), 7..9 canonical-order layouts (systolic, stage by stage), 10..13 lane-map canonical layouts (final pass)
+constexpr int kNumLmsClasses = 16;   // 0..6 and (round 6) 14, 15: search layouts (free summation order); 7..9 canonical-order layouts (systolic, stage by stage), 10..13 lane-map canonical layouts (final pass)
 constexpr int kLmsCanonFirst = 7;
 constexpr int kLmsCanon3First = 10;   // lane-map canonical layouts (no lane-major table copies: off_tabc stays -1)
 

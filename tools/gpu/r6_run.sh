@@ -58,6 +58,19 @@ PY
     timeout 600 python tests/gpu_throughput.py 4096 "" "$TP" > $O/throughput_lms_$2.txt 2>&1; grep "16 taps" $O/throughput_lms_$2.txt | cut -c1-160
     timeout 1800 python -m pytest tests -q -m gpu -x --durations=5 -k "frame_records or headline or evaluate_costs or random_profiles or warm_start or de_and_cma or wide or instalments or configs_3_and_4 or kept_ols or chain or smoke or framecoder_wrapper_writes or batch" > $O/gputests_06_$2.log 2>&1; tail -9 $O/gputests_06_$2.log
     ;;
+  baselines)   # configs[3] / [4] and the default run_single search with the CPU reference timed on THIS box in the same run
+    timeout 1500 python bench.py --mode veryhigh --frames 64 --steps 1 --warmup 0 --no-extras --no-all-cores --cpu-threads-only --verify-sample 2 > $O/baseline_veryhigh_64.json 2> $O/baseline_veryhigh_64.err
+    timeout 1500 python bench.py --mode best --maxnfunc 100 --frames 64 --steps 1 --warmup 0 --no-extras --no-all-cores --cpu-threads-only --verify-sample 2 > $O/baseline_best_e100_64.json 2> $O/baseline_best_e100_64.err
+    timeout 1500 python bench.py --dds-n 0 --frames 256 --steps 1 --warmup 0 --no-extras --no-all-cores --verify-sample 2 > $O/baseline_run_single_256.json 2> $O/baseline_run_single_256.err
+    python - <<'PY'
+import json
+for n in ("veryhigh_64","best_e100_64","run_single_256"):
+    try:
+        d=json.load(open(f"gpurun_out/r06/baseline_{n}.json")); cb=d.get("cpu_baseline") or {}
+        print(n, "GPU", round(d["value"],4), "MSamples/s", round(d["ms_per_step"]/1e3,1), "s bps", round(d["bps"],4), "| CPU", cb.get("value"), "cores", cb.get("cores"), "kind", cb.get("kind"), "ratio", round(d["value"]/cb["value"],1) if cb.get("value") else None, "rec0 equal", cb.get("same_record_as_gpu"))
+    except Exception as e: print(n, "failed", e)
+PY
+    ;;
   bench768)
     timeout 1500 python bench.py --frames 768 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_768_$2.json 2> $O/bench_768_$2.err
     tail -c 1500 $O/bench_768_$2.json
