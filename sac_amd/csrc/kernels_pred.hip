@@ -215,9 +215,14 @@ void launch_ols(hipStream_t s, const WorkItem *d_items, const int *d_idx, int co
 // split differently: the search often makes ONE late stage long (stage 1 up to 3072, stage 2 up to 1280,
 // stage 3 up to 768 taps) or stage 0 alone (up to 5120), which class 1's per-stage caps would send to class 2.
 using LmsA = LmsClass<8, 4, 2, 1>;
-using LmsB = LmsClass<16, 8, 4, 2>;
-using LmsD = LmsClass<10, 12, 5, 3>;
-using LmsE = LmsClass<20, 4, 5, 1>;
+using LmsB = LmsClass<16, 8, 4, 2>;       // (the 512-lane whole-CU layout, class 2: the profile's box maximum)
+// The three 30-slot layouts of 256 lanes (classes 1, 3, 4).  Round 6: re-chosen for the items the five 15- / 22-slot layouts leave over (1 495 of the
+// 23 045 items of a 128-frame search, gpurun_out/r05/search_vn_128.npy): the best triple by exhaustive search over the 60 widest-covering splits takes
+// 1 463 of them, where (16,8,4,2), (10,12,5,3), (20,4,5,1) took 1 292 -- the rest falls to the whole-CU class 2, whose workgroups wait for drained CUs
+// at the end of every generation (203 -> 32 items).
+using LmsB2 = LmsClass<12, 12, 4, 2>;
+using LmsD = LmsClass<18, 6, 4, 2>;
+using LmsE = LmsClass<15, 8, 6, 1>;
 // 5 and 6: 22 slots, the most that still fits 256 VGPRs without scratch overflow, split for a long stage 1
 // or a long stage 0: together they take about 60 % of the search's cascade work (need histogram of the
 // default bench run), leaving ~10 % to the 30-slot layouts
@@ -260,7 +265,7 @@ template <> struct LmsCfg<0> { static constexpr int ROUNDS = 1; using C = LmsA; 
 #ifndef SACAMD_EXP_LMS56_MINB
 #define SACAMD_EXP_LMS56_MINB 3        // round 6: factored step-size table (pred_lms.h) -> 166 registers, 64-sample staging -> 52.4 KB of LDS: three per CU
 #endif
-template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
+template <> struct LmsCfg<1> { static constexpr int ROUNDS = 1; using C = LmsB2; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
 template <> struct LmsCfg<2> { static constexpr int ROUNDS = 1; using C = LmsB; static constexpr int NL = 512, MINB = 1; };
 template <> struct LmsCfg<3> { static constexpr int ROUNDS = 1; using C = LmsD; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
 template <> struct LmsCfg<4> { static constexpr int ROUNDS = 1; using C = LmsE; static constexpr int NL = 256, MINB = SACAMD_EXP_LMS134_MINB; };
@@ -307,7 +312,7 @@ static void launch_lms_c(hipStream_t s, const WorkItem *d_items, const int *d_id
 size_t lms_lds_bytes(int lms_class, const LmsRingCap &rc) {
   switch (lms_class) {
     case 0: return LmsLds<256, LmsA>::bytes(rc.c);
-    case 1: return LmsLds<256, LmsB>::bytes(rc.c);
+    case 1: return LmsLds<256, LmsB2>::bytes(rc.c);
     case 3: return LmsLds<256, LmsD>::bytes(rc.c);
     case 4: return LmsLds<256, LmsE>::bytes(rc.c);
     case 5: return LmsLds<256, LmsX>::bytes(rc.c);
@@ -340,7 +345,7 @@ int lms_class_for(const int *vn, bool canon) {
   if (fits(256, LmsY::c0, LmsY::c1, LmsY::c2, LmsY::c3)) return 6;
   if (fits(256, LmsF::c0, LmsF::c1, LmsF::c2, LmsF::c3)) return 14;
   if (fits(256, LmsG::c0, LmsG::c1, LmsG::c2, LmsG::c3)) return 15;
-  if (fits(256, LmsB::c0, LmsB::c1, LmsB::c2, LmsB::c3)) return 1;
+  if (fits(256, LmsB2::c0, LmsB2::c1, LmsB2::c2, LmsB2::c3)) return 1;
   if (fits(256, LmsD::c0, LmsD::c1, LmsD::c2, LmsD::c3)) return 3;
   if (fits(256, LmsE::c0, LmsE::c1, LmsE::c2, LmsE::c3)) return 4;
   return 2;

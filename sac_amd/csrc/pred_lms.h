@@ -11,6 +11,9 @@
 // in LDS.  Per sample ONE fused sweep does "weight update of step t-1" and "dot + power sum of
 // step t" (the update needs the pre-push history, which is the post-push history shifted by
 // one), then a wave-shuffle / LDS reduction, then the serial mixer chain on wave 0.
+// Round 6: the search sweep (lms_sweep) is one branch-free software pipeline over all slots of the layout with the history loads a few
+// slots ahead; the 22-slot layouts keep the step-size table factored (lms_mtfac); the RLS stage lives in wave 2's registers (rls_dispatch);
+// the mixer's wave-uniform state and the loop-invariant parameters live in LDS -- DESIGN.md 4, "The search cascade since round 6".
 //
 // Arithmetic: the per-tap element operations are the reference's (explicit fma); the small dots of
 // the serial chain use the canonical order (canon.h).  The N-term dot / power sums come in two forms:
@@ -154,7 +157,7 @@ struct LmsLds {
   double *part;     // [2][NL/64][8]
   double *bc;       // [4]: wgrad of each stage
   double *pin, *pout;
-  double *rx, *rw, *rph;     // RLS history / weights mirror / P*x
+  double *rph;               // round 6: the wave-uniform mixer state `us` (the RLS vectors live in wave 2's registers)
   double *P;                 // RLS inverse covariance, row l at P + l * kRlsMax (owned by the lanes of wave 2)
   double *pv;                // stage predictions p[0..3]
   double *exwm;              // expert weights mirror [2][5]
@@ -178,7 +181,7 @@ struct LmsLds {
     if (CANON) d += 64 + 32 + 64 + 32;
     if (CANON == 3) d += (size_t)(NL / 2) * C::c0;     // mutab of the dot lanes, lane-major per wave
     d -= 2 * (NL - chunk());                           // pin / pout hold one chunk
-    d += 2 * (NL / 64) * 8 + 4 + 2 * NL + 3 * kRlsMax + kRlsMax * kRlsMax + 4 + 10 + 16 + 16 + kLibmLdsDoubles;   // part, bc[4], pin/pout, RLS, pv[4], exwm, cst, hs, libm   // pin/pout: NL samples staged per exchange
+    d += 2 * (NL / 64) * 8 + 4 + 2 * NL + kRlsMax + kRlsMax * kRlsMax + 4 + 10 + 16 + 16 + kLibmLdsDoubles;   // part, bc[4], pin/pout, mixer state, RLS P, pv[4], exwm, cst, hs, libm   // pin/pout: NL samples staged per exchange
     return d * sizeof(double) + chunk() * sizeof(int) + 16;
   }
   SA_HD static size_t bytes() {
@@ -201,7 +204,7 @@ struct LmsLds {
     part = d; d += 2 * (NL / 64) * 8;
     bc = d; d += 4;
     pin = d; d += chunk(); pout = d; d += chunk();
-    rx = d; d += kRlsMax; rw = d; d += kRlsMax; rph = d; d += kRlsMax;
+    rph = d; d += kRlsMax;
     P = d; d += kRlsMax * kRlsMax;
     pv = d; d += 4; exwm = d; d += 10; cst = d; d += 16; hs = d; d += 16;
     libm = d; d += kLibmLdsDoubles;
@@ -439,7 +442,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     if (l == 8) { L.cst[8] = p.proj_alpha; L.cst[9] = 1.0 - p.proj_alpha; L.cst[10] = p.mu_mix; L.cst[11] = p.mu_mix_beta; L.cst[12] = 1.0 - p.mu_mix_beta; L.cst[13] = p.lm_alpha; L.cst[14] = (double)p.lo; L.cst[15] = (double)p.hi; }
     if (l < 10) L.exwm[l] = 1.0 / 5;
     if (l < 16) L.hs[l] = (l == 12 || l == 13) ? 0.5 : 0.0;
-    if (l < kRlsMax) { L.rx[l] = 0.0; L.rw[l] = 0.0; L.rph[l] = 0.0; }     // (rx, rw unused since round 6: the RLS vectors live in wave 2's registers; rph = the wave-uniform state `us`, all zero at the start)
+    if (l < kRlsMax) L.rph[l] = 0.0;     // the wave-uniform state `us`: all zero at the start
     mr0[l] = (l >> 6) == 1 ? 1.0 / 5 : 0.0;   // wave 1: LS_ADA expert weights start at 1/5
     mr1[l] = 0.0; mr2[l] = 0.0; mr3[l] = 0.0;
     if (l >= 16 && l < 20) { mr2[l] = p.vmu[l - 16]; mr3[l] = sum_powtab[l - 16]; }
@@ -456,12 +459,6 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
     for (int s = 0; s < 4; s++) { tcm[s] = q_; tcp[s] = q_ + (CANON ? ROUNDS : 1) * C::slots(s) * 256; q_ += 2 * (CANON ? ROUNDS : 1) * C::slots(s) * 256; }
   }
   static_assert(CANON != 2 || (NL == kCanonNL && C::c0 == canon_slots(0) && C::c1 == canon_slots(1) && C::c2 == canon_slots(2) && C::c3 == canon_slots(3)), "lane-major tables are laid out for the (9,5,3,1) x 256 layout");
-  int rmax8 = 0, rmax4 = 0;     // longest transform_reduce tails over the four stages (dot: n mod 8 or n < 8; power sum: n mod 4 or n < 8)
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const int t8 = ns[s] >= 8 ? ns[s] & 7 : ns[s], t4 = ns[s] >= 8 ? ns[s] & 3 : ns[s];
-    rmax8 = t8 > rmax8 ? t8 : rmax8; rmax4 = t4 > rmax4 ? t4 : rmax4;
-  }
   // ring s starts ro1 + .. + ro_s doubles after ring[0]
   const int ro1 = (int)(L.ring[1] - L.ring[0]), ro2 = (int)(L.ring[2] - L.ring[1]), ro3 = (int)(L.ring[3] - L.ring[2]);
   const int rofs[4] = {0, ro1, ro1 + ro2, ro1 + ro2 + ro3};                                                    // search sweep: ring s = ring[0] + rofs[s] (one LDS base)
@@ -785,8 +782,7 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
             auto hist = [&](int tap) { tap = tap < last ? tap : last; int in = ps + tap; if (in >= cs) in -= cs; return r0[ro + ridx(in)]; };
             const double *tw = L.tailw + (par * 4 + s) * 8, *tpw = L.tailpw + s * 8;
             // dot: chain sums, then the transform_reduce tail (canon.h tr_dot) on register operands, selects instead of
-            // branches; the power sum likewise afterwards (the two halves share their registers).  rmax8 / rmax4: the
-            // longest tail of any stage (uniform), so that short tails load nothing they do not need.
+            // branches; the power sum likewise afterwards.
             a = 0.0; b = 0.0;
             // Round 6: ALL operands of the two tails are requested first -- chain sums, the (up to seven) tail taps' history and weights,
             // the power-sum chains and powtab entries: 33 loads, one LDS round trip -- and the arithmetic follows behind a scheduling

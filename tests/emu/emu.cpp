@@ -107,9 +107,9 @@ API int emu_predict(int nch, int total, const int32_t *samples, const int32_t *s
     else if (vn[0] <= 3328 && vn[1] <= 1280 && vn[2] <= 768 && vn[3] <= 256) run_lms<LmsClass<13, 5, 3, 1>>(p, sp, tab.data(), self, n, ps);
     else if (vn[0] <= 3584 && vn[1] <= 512 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<14, 2, 4, 2>>(p, sp, tab.data(), self, n, ps);     // 14, 15: round-6 layouts
     else if (vn[0] <= 2304 && vn[1] <= 1280 && vn[2] <= 1280 && vn[3] <= 768) run_lms<LmsClass<9, 5, 5, 3>>(p, sp, tab.data(), self, n, ps);
-    else if (vn[0] <= 4096 && vn[1] <= 2048 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<16, 8, 4, 2>>(p, sp, tab.data(), self, n, ps);
-    else if (vn[0] <= 2560 && vn[1] <= 3072 && vn[2] <= 1280 && vn[3] <= 768) run_lms<LmsClass<10, 12, 5, 3>>(p, sp, tab.data(), self, n, ps);
-    else if (vn[0] <= 5120 && vn[1] <= 1024 && vn[2] <= 1280 && vn[3] <= 256) run_lms<LmsClass<20, 4, 5, 1>>(p, sp, tab.data(), self, n, ps);
+    else if (vn[0] <= 3072 && vn[1] <= 3072 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<12, 12, 4, 2>>(p, sp, tab.data(), self, n, ps);
+    else if (vn[0] <= 4608 && vn[1] <= 1536 && vn[2] <= 1024 && vn[3] <= 512) run_lms<LmsClass<18, 6, 4, 2>>(p, sp, tab.data(), self, n, ps);
+    else if (vn[0] <= 3840 && vn[1] <= 2048 && vn[2] <= 1536 && vn[3] <= 256) run_lms<LmsClass<15, 8, 6, 1>>(p, sp, tab.data(), self, n, ps);
     else run_lms<LmsClass<16, 8, 4, 2>, 512>(p, sp, tab.data(), self, n, ps);   // as the launcher: 512 lanes
     std::vector<double> tables(kBiasSlabDoubles);
     bias_stage(p, self, n, ps, stats[3 * ch_self + 2], err + (size_t)ch_self * n, pred ? pred + (size_t)ch_self * n : nullptr, tables.data());
