@@ -757,87 +757,70 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
         if (!dec) { h_plpc = L.pin[tt]; h_sv = L.sv[tt]; }
       });
       ex.wave_par(0, [&](int l) {
-        if (l >= 16 && l < 20) {   // cross-wave totals of stage l-16, waves in order (lanes 16..19 own the stage gains)
-          const int s = l - 16;
-          double a, b;
-          if constexpr (!CANON) {
+        if constexpr (!CANON) {
+          if (l >= 16 && l < 20) {   // cross-wave totals of stage l-16, waves in order (lanes 16..19 own the stage gains)
+            const int s = l - 16;
             double pa_[NW], pb_[NW];
 #pragma unroll
             for (int w = 0; w < NW; w++) { pa_[w] = L.part[(par * NW + w) * 8 + s]; pb_[w] = L.part[(par * NW + w) * 8 + 4 + s]; }
             SA_SCHED_FENCE();                  // all partial sums requested before the first addition
-            a = pa_[0]; b = pb_[0];
+            double a = pa_[0], b = pb_[0];
 #pragma unroll
             for (int w = 1; w < NW; w++) { a = a + pa_[w]; b = b + pb_[w]; }
-          } else {
-            // slmath::dot: sum1 + sum2 lane-wise, ((b0+b1)+b2)+b3, += transform_reduce tail; calc_s2pow alike.
-            // The rings are addressed as offsets from ring[0] (one LDS base, no pointer select) and every load of
-            // the tails is issued before the arithmetic.
+            dots_r[l] = a; spow_r[l] = b;      // (the head takes the stage predictions from these lanes by v_readlane: no LDS hand-over)
+          }
+        } else {
+          // slmath::dot: sum1 + sum2 lane-wise, ((b0+b1)+b2)+b3, += transform_reduce tail; calc_s2pow alike (common/math.h:130-191).
+          // Round 6: EIGHT lanes, one instruction stream -- lane 16 + s forms the dot total of stage s, lane 20 + s its power sum.  The two
+          // have the same shape once the operands are named A, B: dot A = x, B = w; power sum A = x x, B = powtab; chains q[c] + q[c + 4]
+          // with -0.0 in the power sum's upper four (x + -0.0 = x for every x); so both run side by side where lanes 16..19 used to do
+          // one after the other.  All 22 operands of a lane are requested first (tap indices clamped to the stage's last tap, the tail
+          // weight slots always written: unused operands are finite, the selects below discard them), then the arithmetic behind a
+          // scheduling fence.  The power sum reaches the gains lane 16 + s through pv[s] (read behind the head barrier).
+          if (l >= 16 && l < 24) {
+            const int s = (l - 16) & 3;
+            const bool pw = l >= 20;
             const int nsl = s == 0 ? ns[0] : (s == 1 ? ns[1] : (s == 2 ? ns[2] : ns[3]));
             const int cs = s == 0 ? cap[0] : (s == 1 ? cap[1] : (s == 2 ? cap[2] : cap[3]));
             const int ps = s == 0 ? pos[0] : (s == 1 ? pos[1] : (s == 2 ? pos[2] : pos[3]));
             const int ro = (s >= 1 ? ro1 : 0) + (s >= 2 ? ro2 : 0) + (s >= 3 ? ro3 : 0);   // sums, not a select among captured variables (which would pin the closure, and everything it references, in scratch)
             const double *r0 = L.ring[0];
             const int K8 = nsl >= 8 ? nsl >> 3 : 0, K4 = nsl >= 8 ? nsl >> 2 : 0;
-            const int r8 = nsl - 8 * K8, r4 = nsl - 4 * K4, last = nsl - 1;
+            const int last = nsl - 1;
+            const int t0 = pw ? 4 * K4 : 8 * K8;              // first tail tap
+            const int rl = nsl - t0;                          // tail length: < 8 (dot) resp. < 4 (power sum), or the whole stage when n < 8
             auto hist = [&](int tap) { tap = tap < last ? tap : last; int in = ps + tap; if (in >= cs) in -= cs; return r0[ro + ridx(in)]; };
-            const double *tw = L.tailw + (par * 4 + s) * 8, *tpw = L.tailpw + s * 8;
-            // dot: chain sums, then the transform_reduce tail (canon.h tr_dot) on register operands, selects instead of
-            // branches; the power sum likewise afterwards.
-            a = 0.0; b = 0.0;
-            // Round 6: ALL operands of the two tails are requested first -- chain sums, the (up to seven) tail taps' history and weights,
-            // the power-sum chains and powtab entries: 33 loads, one LDS round trip -- and the arithmetic follows behind a scheduling
-            // fence.  Interleaved by the compiler (a load next to each use, conditional on the tail length) this section took 3 500
-            // cycles per sample, a third of the final-pass cascade's sample time (probe build SACAMD_EXP_TICK_TOTALS).  The loads
-            // are unconditional: a tap index is clamped to the stage's last tap and the tail-weight slots are always written, so
-            // the unused operands are finite and the selects below discard them.  The power sum's tail taps 4 K4 .. n-1 are the
-            // dot tail's taps 8 K8 .. n-1 from offset 4 K4 - 8 K8 (0 or 4) on: no second set of history loads.
-            double q[8], r[4], xt[7], wt[7], pt[7];
+            const double *qs = pw ? L.psum + (par * 4 + s) * 4 : L.csum + (par * 4 + s) * 8;     // (one base: both arrays lie in the same LDS block, psum behind csum)
+            const double *bs = pw ? L.tailpw + s * 8 : L.tailw + (par * 4 + s) * 8;
+            double q[8], xa[7], bb[7];
 #pragma unroll
-            for (int u = 0; u < 8; u++) q[u] = L.csum[(par * 4 + s) * 8 + u];
+            for (int u = 0; u < 8; u++) q[u] = qs[u];
 #pragma unroll
-            for (int u = 0; u < 4; u++) r[u] = L.psum[(par * 4 + s) * 4 + u];
-#pragma unroll
-            for (int u = 0; u < 7; u++) { xt[u] = hist(8 * K8 + u); wt[u] = tw[u]; pt[u] = tpw[u]; }
+            for (int u = 0; u < 7; u++) { xa[u] = hist(t0 + u); bb[u] = bs[u]; }
             SA_SCHED_FENCE();
-            {
-              if (K8 > 0) {
-                const double q0 = q[0] + q[4], q1 = q[1] + q[5], q2 = q[2] + q[6], q3 = q[3] + q[7];
-                a = ((q0 + q1) + q2) + q3;
-              }
-              const bool g4 = r8 >= 4;
-              const double v1 = fma(xt[1], wt[1], xt[0] * wt[0]), v2 = fma(xt[3], wt[3], xt[2] * wt[2]);
-              double init = g4 ? 0.0 + (v1 + v2) : 0.0;
-              const int rem = g4 ? r8 - 4 : r8;
-              const double e0 = g4 ? xt[4] : xt[0], e1 = g4 ? xt[5] : xt[1], e2 = g4 ? xt[6] : xt[2];
-              const double f0 = g4 ? wt[4] : wt[0], f1 = g4 ? wt[5] : wt[1], f2 = g4 ? wt[6] : wt[2];
-              const double i2 = (init + e0 * f0) + e1 * f1;
-              init = rem >= 2 ? i2 : init;
-              const double el = rem >= 2 ? e2 : e0, fl = rem >= 2 ? f2 : f0;
-              const double i3 = fma(el, fl, init);
-              init = (rem & 1) ? i3 : init;
-              a = a + init;
-            }
-            {
-              const bool o4 = 4 * K4 != 8 * K8;        // the power tail starts four taps into the dot tail (then it has at most three terms)
-              double xp[7];
 #pragma unroll
-              for (int u = 0; u < 7; u++) xp[u] = (o4 && u < 3) ? xt[u + 4] : xt[u];
-              if (K8 > 0) b = ((r[0] + r[1]) + r[2]) + r[3];
-              const bool g4 = r4 >= 4;
-              const double v1 = fma(xp[1] * xp[1], pt[1], (xp[0] * xp[0]) * pt[0]), v2 = fma(xp[3] * xp[3], pt[3], (xp[2] * xp[2]) * pt[2]);
-              double init = g4 ? 0.0 + (v1 + v2) : 0.0;
-              const int rem = g4 ? r4 - 4 : r4;
-              const double e0 = g4 ? xp[4] : xp[0], e1 = g4 ? xp[5] : xp[1], e2 = g4 ? xp[6] : xp[2];
-              const double f0 = g4 ? pt[4] : pt[0], f1 = g4 ? pt[5] : pt[1], f2 = g4 ? pt[6] : pt[2];
-              const double i2 = (init + (e0 * e0) * f0) + (e1 * e1) * f1;
-              init = rem >= 2 ? i2 : init;
-              const double el = rem >= 2 ? e2 : e0, fl = rem >= 2 ? f2 : f0;
-              const double i3 = fma(el * el, fl, init);
-              init = (rem & 1) ? i3 : init;
-              b = b + init;
+            for (int u = 4; u < 8; u++) q[u] = pw ? -0.0 : q[u];
+#pragma unroll
+            for (int u = 0; u < 7; u++) xa[u] = xa[u] * (pw ? xa[u] : 1.0);      // A: x (x * 1.0 = x exactly) resp. x x
+            double tot = 0.0;
+            if (K8 > 0) {
+              const double q0 = q[0] + q[4], q1 = q[1] + q[5], q2 = q[2] + q[6], q3 = q[3] + q[7];
+              tot = ((q0 + q1) + q2) + q3;
             }
+            const bool g4 = rl >= 4;
+            const double v1 = fma(xa[1], bb[1], xa[0] * bb[0]), v2 = fma(xa[3], bb[3], xa[2] * bb[2]);
+            double init = g4 ? 0.0 + (v1 + v2) : 0.0;
+            const int rem = g4 ? rl - 4 : rl;
+            const double e0 = g4 ? xa[4] : xa[0], e1 = g4 ? xa[5] : xa[1], e2 = g4 ? xa[6] : xa[2];
+            const double f0 = g4 ? bb[4] : bb[0], f1 = g4 ? bb[5] : bb[1], f2 = g4 ? bb[6] : bb[2];
+            const double i2 = (init + e0 * f0) + e1 * f1;
+            init = rem >= 2 ? i2 : init;
+            const double el = rem >= 2 ? e2 : e0, fl = rem >= 2 ? f2 : f0;
+            const double i3 = fma(el, fl, init);
+            init = (rem & 1) ? i3 : init;
+            tot = tot + init;
+            if (pw) L.pv[s] = tot; else dots_r[l] = tot;
           }
-          dots_r[l] = a; spow_r[l] = b;      // (the head takes the stage predictions from these lanes by v_readlane: no LDS hand-over)
         }
       });
 #if defined(SACAMD_EXP_TICK_TOTALS)
@@ -973,7 +956,8 @@ SA_HD void lms_stage(E &ex, const ChanParam &p, const double *sum_powtab, const 
           // one LDS base + offset: a select among the four ring pointers becomes a load through a selected ADDRESS
           // inside the LmsLds object, which pins that object (and every pointer in it) in scratch memory
           double *rg = L.ring[0] + ((sl >= 1 ? ro1 : 0) + (sl >= 2 ? ro2 : 0) + (sl >= 3 ? ro3 : 0));
-          L.bc[sl] = vmu_r[l] * (bps - dots_r[l]) * spt_r[l] / (spow_r[l] + 1.0);
+          const double spow = CANON ? L.pv[sl] : spow_r[l];       // canonical layouts: the power sum was formed by lane 20 + sl (totals above)
+          L.bc[sl] = vmu_r[l] * (bps - dots_r[l]) * spt_r[l] / (spow + 1.0);
           int np = ps - 1; if (np < 0) np += cs;
           rg[ridx(np)] = bps;
           if (LM ? np < EXT3 : np == 0) rg[ridx(cs + np)] = bps;        // mirror: ring[in + 1] (lane-map layout: a lane's whole window) needs no wrap in the sweep
