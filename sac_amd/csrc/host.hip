@@ -285,7 +285,7 @@ __attribute__((constructor)) void sacamd_on_load() {
     }
   }
 }
-bool hw_queues_ok(std::string *why) {
+void warn_about_hw_queues() {
   static std::once_flag warned;
   const char *e = std::getenv("GPU_MAX_HW_QUEUES");
   const int have = e ? std::atoi(e) : 4;
@@ -296,8 +296,6 @@ bool hw_queues_ok(std::string *why) {
   else if (have < kHwQueuesNeeded)
     std::call_once(warned, [have] { std::fprintf(stderr, "sac_amd: GPU_MAX_HW_QUEUES=%d (set by the caller): the stream pool wants >= %d hardware queues; kernel classes will "
                                                          "serialise on the ones there are.\n", have, kHwQueuesNeeded); });
-  (void)why;
-  return true;
 }
 
 struct DevStreams {
@@ -696,7 +694,7 @@ API int sacamd_ctx_create(int device, int nch, int max_framesize, int max_frames
   if (!out) return SACAMD_ERR_ARG;
   *out = nullptr;
   if (nch < 1 || nch > 2 || max_framesize < 1 || max_frames < 1) return SACAMD_ERR_ARG;
-  { std::string why; if (!hw_queues_ok(&why)) { std::fprintf(stderr, "sac_amd: %s\n", why.c_str()); return SACAMD_ERR_STATE; } }
+  warn_about_hw_queues();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SACAMD_ERR_NOGPU;
   hipDeviceProp_t prop;
