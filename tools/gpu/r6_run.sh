@@ -2,7 +2,7 @@
 # round 6 GPU calls, one parameterised script: tools/gpu/r6_run.sh <step> (run on the GPU box through gpurun)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r06; mkdir -p $O
-TP='1280,256,32,4;1500,2500,900,400;3300,1200,700,250;3900,1900,900,400'
+TP='1280,256,32,4;1500,2500,900,400;3300,1200,700,250;3000,2900,900,400'     # 15-slot, 22-slot (6,10,4,2), mostly 30-slot, 30-slot (12,12,4,2) [until the layouts were re-chosen the last one was 3900,1900,900,400]
 case "$1" in
   sweep1)   # pipelined search sweep: parity subset, section cycles, saturated throughput (base + prefetch depth 4)
     timeout 900 python -m pytest tests -q -m gpu -x -k "random_profiles or predictor_stages or evaluate_costs or headline or kept_ols" > $O/gputests_01_sweep_subset.log 2>&1
