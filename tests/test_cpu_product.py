@@ -484,6 +484,37 @@ def test_canonical_cascade_layout_boundaries_emulated_vs_oracle(emu, orc, taps):
     assert np.array_equal(err, oe)
 
 
+# one stage-length tuple per search layout of the launcher (lms_class_for, kernels_pred.hip), each at a capacity edge of
+# that layout: 15 slots (8,4,2,1); 22 slots (6,10,4,2) (13,5,3,1) (14,2,4,2) (9,5,5,3) -- the ones that use the factored
+# step-size table; 30 slots (12,12,4,2) (18,6,4,2) (15,8,6,1); 512 lanes (16,8,4,2)
+_SEARCH_LAYOUT_TAPS = [(2048, 1024, 512, 256), (1536, 2560, 1024, 512), (3328, 1280, 768, 256), (3584, 512, 1024, 512),
+                       (2304, 1280, 1280, 768), (3072, 3072, 1024, 512), (4608, 1536, 1024, 512), (3840, 2048, 1536, 256),
+                       (4609, 1537, 1025, 513), (1537, 1025, 513, 257), (3329, 7, 769, 3)]
+
+
+@pytest.mark.parametrize("taps", _SEARCH_LAYOUT_TAPS)
+def test_search_cascade_layouts_emulated_vs_oracle(emu, orc, taps):
+    """The search-mode cascade (k = optk) in every layout the launcher can pick, at the layout's capacity and one past the
+    previous one's: emulated kernel body vs oracle.  The OLS stage is bit-exact; the NLMS sums are free-order (and, in the
+    22-slot layouts, use the factored step-size table), so the stage sum is held to the search tolerance of DESIGN.md and
+    the residuals to the few samples where that moves a rounding."""
+    from sac_amd.synth import synth_pcm
+    n = 2600
+    raw = synth_pcm(n, 1, 500 + sum(taps) % 17, 8000)
+    g = np.ascontiguousarray(orc.profile()[:, 2].copy(), np.float32)
+    g[28], g[29], g[30], g[37] = taps
+    smp, stats = center_frame(raw)
+    plpc = np.zeros((1, n)); psum = np.zeros((1, n)); err = np.zeros((1, n), np.int32); pred = np.zeros((1, n), np.int32)
+    rc = emu.emu_predict(1, n, _vp(np.ascontiguousarray(smp, np.int32)), _vp(np.ascontiguousarray(stats, np.int32)), _vp(g), 0, n, 1, 4,
+                         _vp(plpc), _vp(psum), _vp(err), _vp(pred))
+    assert rc == 0
+    pd, ol, om, oe = orc.predict_trace(smp, stats, g, 0, n, 1)
+    want = ol + om
+    assert np.array_equal(plpc.view(np.uint64), ol.view(np.uint64))
+    assert np.max(np.abs(psum - want) / (np.abs(want) + 1.0)) < 1e-9
+    assert int((err != oe).sum()) <= n // 200 and int(np.max(np.abs(err - oe))) <= 1
+
+
 @pytest.mark.parametrize("nA,nM0,opt", [(5, 0, 0), (16, 1, 1), (17, 0, 0), (24, 0, 1), (25, 7, 0), (32, 1, 1), (32, 8, 0), (32, 15, 1), (32, 16, 0),
                                         (32, 17, 1), (32, 24, 0), (32, 31, 1), (32, 32, 0), (32, 32, 1)])
 def test_register_resident_ols_kernel_body_vs_oracle(emu, orc, nA, nM0, opt):
