@@ -623,13 +623,24 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     // longest first onto the least loaded stream of the group: when a group has more launches than streams, the small launches
     // queue behind the SMALLEST of the big ones (round-robin put them behind the biggest: a 0.4-s launch of 40 items then started
     // when the 8-s launch ahead of it had ended, and the generation ended 0.3-0.8 s late: profiles/r04/README.md 7)
+    // A launch of a few items lasts as long as one item whatever its work, and every throughput-bound launch of a group ends when the
+    // chip drains: a small launch goes to a stream WITHOUT a throughput-bound launch while the group has one, and small launches are
+    // balanced by their number, not by their taps (round 6, final pass at 1536 frames: four 512-lane lane-map launches of 1-5 items,
+    // 6-14 s each, had queued on one stream behind one another and ended 1.6 s after everything else: launch_trace_1536_trace.txt).
+    const double small_w = (want_pred ? 1.5e6 : 5e5) * (double)items[0].n;     // taps x samples: about one item's latency at the chip's rate
     std::vector<double> load(sacamd_ctx::kSide, 0.0);
+    std::vector<int> nbig(sacamd_ctx::kSide, 0);
     for (size_t q : lms_order) {
       const int g = lms_launches[q].group;
+      const bool big = work[q] >= small_w;
+      auto better = [&](int a, int b) {
+        if (!big && (nbig[a] > 0) != (nbig[b] > 0)) return nbig[a] == 0;
+        return load[a] < load[b]; };
       int best = pool[g][0];
-      for (int si : pool[g]) if (load[si] < load[best]) best = si;
+      for (int si : pool[g]) if (better(si, best)) best = si;
       lms_stream[q] = best;
-      load[best] += std::min(work[q], 1e290) + 1.0;
+      load[best] += big ? std::min(work[q], 1e290) + 1.0 : small_w;
+      nbig[best] += big;
     }
   }
   auto launch_one = [&](size_t q) -> int {

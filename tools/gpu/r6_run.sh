@@ -46,6 +46,14 @@ PY
     for t in 1280,256,32,4 3383,1168,614,273 5400,64,16,8; do timeout 200 python tests/gpu_dbg_canon.py $t 6000; done > $O/canon_latency_$2.txt 2>&1; cat $O/canon_latency_$2.txt
     timeout 900 python -m pytest tests -q -m gpu -x -k "canonical or predictor_stages or frame_records or decoder_inverts or evaluate_costs or random_profiles or warm_start" > $O/gputests_05_$2.log 2>&1; tail -3 $O/gputests_05_$2.log
     ;;
+  trace1536)   # one 1536-frame step with the launch trace on (per-class launch start / duration of every generation)
+    SACAMD_TRACE=1 timeout 1500 python bench.py --frames 1536 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_1536_$2.json 2> $O/bench_1536_$2.err
+    grep "sacamd trace" $O/bench_1536_$2.err > $O/launch_trace_1536_$2.txt; wc -l $O/launch_trace_1536_$2.txt
+    python - <<PY
+import json
+d=[json.loads(l) for l in open("gpurun_out/r06/bench_1536_$2.json") if l.startswith("{")][-1]; print(d["value"], d["ms_per_step"], d["bps"], d["kernel_ms"])
+PY
+    ;;
   bench1536)
     timeout 1500 python bench.py --frames 1536 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --verify-sample 0 > $O/bench_1536_$2.json 2> $O/bench_1536_$2.err
     python - <<PY
