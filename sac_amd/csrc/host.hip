@@ -627,7 +627,9 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
     // chip drains: a small launch goes to a stream WITHOUT a throughput-bound launch while the group has one, and small launches are
     // balanced by their number, not by their taps (round 6, final pass at 1536 frames: four 512-lane lane-map launches of 1-5 items,
     // 6-14 s each, had queued on one stream behind one another and ended 1.6 s after everything else: launch_trace_1536_trace.txt).
-    const double small_w = (want_pred ? 1.5e6 : 5e5) * (double)items[0].n;     // taps x samples: about one item's latency at the chip's rate
+    double n_mean = 0;
+    for (const WorkItem &it : items) n_mean += (double)it.n / count;
+    const double small_w = (want_pred ? 1.5e6 : 5e5) * n_mean;     // taps x samples: about one item's latency at the chip's rate
     std::vector<double> load(sacamd_ctx::kSide, 0.0);
     std::vector<int> nbig(sacamd_ctx::kSide, 0);
     for (size_t q : lms_order) {
