@@ -204,6 +204,19 @@ int sacamd_decode_frames(sacamd_ctx *ctx, int nframes, int framesize, const uint
  * sacamd_gather_records (the only communication on this path). */
 int sacamd_assign_frames(const double *cost, int nframes, int world, int *owner);
 
+/* ---- cascade launch plan (host only) ------------------------------------------------------------
+ * The planner sacamd_encode_frames / sacamd_evaluate use for the cascade launches of one predictor pass
+ * (sac_amd/csrc/launch_plan.h), callable without a GPU.  Replaces: nothing in the reference, whose FrameCoder
+ * evaluates one candidate at a time (libsac.cpp:323-344); the batch's launches are this library's own.
+ * Launch q belongs to group[q] (a group waits for its own OLS classes) and has work[q] (taps x samples summed
+ * over its items; 1e300 = the whole-CU layout); group g may use the streams pool[pool_begin[g] .. pool_begin[g+1])
+ * (ids < 4096).  order[] = the launches in issue order, stream[q] = the stream of launch q: throughput-bound
+ * launches (work >= small_work) longest first onto the least loaded stream, small ones onto streams without a
+ * throughput-bound launch where the pool has one, balanced by their number.  SACAMD_ERR_ARG for a launch
+ * whose group has no streams.  (ABI version 7.) */
+int sacamd_plan_cascade_streams(int nlaunches, const int *group, const double *work, int ngroups, const int *pool_begin, const int *pool,
+                                double small_work, int *order, int *stream);
+
 /* ---- multi-GPU record gather (RCCL over xGMI) ----------------------------------------------------
  * Replaces: nothing in the single-process reference; what is gathered is what FrameCoder::WriteEncoded
  * (libsac.cpp:565-578) appends to the file, frame after frame, in Codec::EncodeFile's loop (:822-829) -- rank 0 ends up with

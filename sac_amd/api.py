@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "sacamd_encode_frames", "sacamd_debug_predict", "sacamd_debug_bitplane", "sacamd_debug_cost",
     "sacamd_plan_subframes", "sacamd_subframes_from_states", "sacamd_kernel_times", "sacamd_class_times", "sacamd_eval_stats", "sacamd_debug_ols_profile", "sacamd_abi_version", "sacamd_progress", "sacamd_search_frames", "sacamd_assign_frames",
     "sacamd_decode_frames", "sacamd_comm_unique_id", "sacamd_comm_create", "sacamd_comm_destroy", "sacamd_comm_last_error",
-    "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_debug_libm", "sacamd_predictor_streams", "sacamd_get_encoded_variant", "sacamd_get_residuals_map",
+    "sacamd_gather_records", "sacamd_gather_records_via", "sacamd_plan_cascade_streams", "sacamd_debug_libm", "sacamd_predictor_streams", "sacamd_get_encoded_variant", "sacamd_get_residuals_map",
     "sacamd_search_frames_resume", "sacamd_search_state_bytes",
 ]
 
@@ -66,7 +66,7 @@ def make_cfg(mode="normal", num_threads=0, reset=1, sparse_pcm=1, zero_mean=1, f
 _lib = None
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class PredTParam(ctypes.Structure):
@@ -161,6 +161,23 @@ def assign_frames(cost, world: int) -> np.ndarray:
     if rc != 0:
         raise SacAmdError(f"sacamd_assign_frames failed ({rc})")
     return owner
+
+
+def plan_cascade_streams(group, work, pools, small_work: float):
+    """(order, stream) of the cascade launches of one predictor pass (sacamd_plan_cascade_streams; host only, no device):
+    launch q of group[q] with work[q]; pools[g] = stream ids group g may use."""
+    lib = load_library()
+    g = np.ascontiguousarray(group, np.int32); w = np.ascontiguousarray(work, np.float64)
+    begin = np.zeros(len(pools) + 1, np.int32)
+    for i, p in enumerate(pools):
+        begin[i + 1] = begin[i] + len(p)
+    flat = np.ascontiguousarray([s for p in pools for s in p] or [0], np.int32)
+    order = np.zeros(max(len(g), 1), np.int32); stream = np.zeros(max(len(g), 1), np.int32)
+    lib.sacamd_plan_cascade_streams.argtypes = [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_void_p]
+    rc = lib.sacamd_plan_cascade_streams(len(g), _vp(g), _vp(w), len(pools), _vp(begin), _vp(flat), float(small_work), _vp(order), _vp(stream))
+    if rc != 0:
+        raise SacAmdError(f"sacamd_plan_cascade_streams failed ({rc})")
+    return order[:len(g)].copy(), stream[:len(g)].copy()
 
 
 # ---- multi-GPU record gather (include/sac_amd.h "multi-GPU record gather")

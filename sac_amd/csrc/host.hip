@@ -30,6 +30,7 @@
 #include "dds_host.h"
 #include "search_host.h"
 #include "kernels.h"
+#include "launch_plan.h"
 #include "params.h"
 #include "pred_tables.h"
 
@@ -593,24 +594,19 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
   HIPCHK(c, hipEventRecord(c->ev_join[kMark], side[kMark]));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[kMark], 0));
   bool lms_used[sacamd_ctx::kSide] = {};
-  // Stream of every cascade launch.  Launches on one stream run one after the other, and a cascade launch is as long as its
-  // slowest item whatever its size, so the launches that become ready together should sit on different streams, the longest
-  // first.  Search (two groups): group 0 (items whose OLS class is one of the fast ones) takes the four cascade streams and
-  // the streams of the fast OLS classes -- those kernels are exactly what the group waits for anyway; group 1 takes the
-  // streams of the slow OLS classes.  Within a group the whole-CU layout (class 2: its workgroups need a drained CU) goes
-  // first, then the launches by descending work.
-  std::vector<int> lms_stream(lms_launches.size());
-  std::vector<size_t> lms_order(lms_launches.size());
-  std::iota(lms_order.begin(), lms_order.end(), (size_t)0);
+  // Stream of every cascade launch (rules and their measurements: launch_plan.h).  Search (two groups): group 0 (items whose OLS
+  // class is one of the fast ones) takes the four cascade streams and the streams of the fast OLS classes -- those kernels are
+  // exactly what the group waits for anyway; group 1 takes the streams of the slow OLS classes.
+  std::vector<int> lms_stream;
+  std::vector<size_t> lms_order;
   {
-    std::vector<double> work(lms_launches.size(), 0.0);
+    std::vector<CascadePlanIn> plan(lms_launches.size());
     for (size_t q = 0; q < lms_launches.size(); q++) {
       const LmsLaunch &ll = lms_launches[q];
-      for (int i = 0; i < ll.count; i++) if (flat[ll.first + i] >= 0) work[q] += (double)taps(flat[ll.first + i]);
-      if (ll.cls == 2) work[q] = 1e300;
+      double w = 0;
+      for (int i = 0; i < ll.count; i++) if (flat[ll.first + i] >= 0) w += (double)taps(flat[ll.first + i]);
+      plan[q] = {ll.group, ll.cls == 2 ? 1e300 : w};
     }
-    std::stable_sort(lms_order.begin(), lms_order.end(), [&](size_t a, size_t b) {
-      return lms_launches[a].group != lms_launches[b].group ? lms_launches[a].group < lms_launches[b].group : work[a] > work[b]; });
     // streams a group's launches may use: the four cascade streams are shared by all groups; search: group 0 also takes the streams
     // of the fast OLS classes (those kernels are exactly what it waits for), group 1 those of the slow classes; final pass: group k
     // takes the stream of OLS class k
@@ -620,30 +616,10 @@ int run_predict(sacamd_ctx *c, std::vector<WorkItem> &items, bool want_pred) {
       else if (g == 0) { for (int k = kNumOlsClasses; k < kMark; k++) pool[0].push_back(k); for (int k = 0; k < kFastOls; k++) pool[0].push_back(k); }
       else for (int k = kFastOls; k < kNumOlsClasses; k++) pool[1].push_back(k);
     }
-    // longest first onto the least loaded stream of the group: when a group has more launches than streams, the small launches
-    // queue behind the SMALLEST of the big ones (round-robin put them behind the biggest: a 0.4-s launch of 40 items then started
-    // when the 8-s launch ahead of it had ended, and the generation ended 0.3-0.8 s late: profiles/r04/README.md 7)
-    // A launch of a few items lasts as long as one item whatever its work, and every throughput-bound launch of a group ends when the
-    // chip drains: a small launch goes to a stream WITHOUT a throughput-bound launch while the group has one, and small launches are
-    // balanced by their number, not by their taps (round 6, final pass at 1536 frames: four 512-lane lane-map launches of 1-5 items,
-    // 6-14 s each, had queued on one stream behind one another and ended 1.6 s after everything else: launch_trace_1536_trace.txt).
     double n_mean = 0;
     for (const WorkItem &it : items) n_mean += (double)it.n / count;
     const double small_w = (want_pred ? 1.5e6 : 5e5) * n_mean;     // taps x samples: about one item's latency at the chip's rate
-    std::vector<double> load(sacamd_ctx::kSide, 0.0);
-    std::vector<int> nbig(sacamd_ctx::kSide, 0);
-    for (size_t q : lms_order) {
-      const int g = lms_launches[q].group;
-      const bool big = work[q] >= small_w;
-      auto better = [&](int a, int b) {
-        if (!big && (nbig[a] > 0) != (nbig[b] > 0)) return nbig[a] == 0;
-        return load[a] < load[b]; };
-      int best = pool[g][0];
-      for (int si : pool[g]) if (better(si, best)) best = si;
-      lms_stream[q] = best;
-      load[best] += big ? std::min(work[q], 1e290) + 1.0 : small_w;
-      nbig[best] += big;
-    }
+    if (!plan_cascade_streams(plan, pool, small_w, lms_order, lms_stream)) return fail(c, SACAMD_ERR_STATE, "cascade launch without a stream pool");   // launch_plan.h
   }
   auto launch_one = [&](size_t q) -> int {
     const LmsLaunch &ll = lms_launches[q];
@@ -687,7 +663,7 @@ void search_window(const sacamd_ctx *c, const sacamd_cfg *cfg, int f, int *start
 }  // namespace
 
 // ================================================================== context
-API int sacamd_abi_version(void) { return 6; }   // 6: sacamd_search_frames_resume, sacamd_search_state_bytes
+API int sacamd_abi_version(void) { return 7; }   // 7: sacamd_plan_cascade_streams; 6: sacamd_search_frames_resume, sacamd_search_state_bytes
 // (history)   // 2: sacamd_class_times takes a capacity, 16 cascade classes; 3: record gather (sacamd_comm_*, sacamd_gather_records*); 4: the gather's first all-gather carries 4 words per rank (ranks of different builds must not meet), sacamd_debug_libm
 
 API void sacamd_default_cfg(sacamd_cfg *cfg) {
@@ -1254,6 +1230,22 @@ API int sacamd_assign_frames(const double *cost, int nframes, int world, int *ow
     for (int q = 1; q < world; q++) if (load[q] < load[r]) r = q;
     load[r] += cost[f]; owner[f] = r;
   }
+  return 0;
+}
+
+API int sacamd_plan_cascade_streams(int nlaunches, const int *group, const double *work, int ngroups, const int *pool_begin, const int *pool,
+                                    double small_work, int *order, int *stream) {
+  if (nlaunches < 0 || ngroups < 1 || !pool_begin || !pool || small_work < 0 || (nlaunches && (!group || !work || !order || !stream))) return SACAMD_ERR_ARG;
+  std::vector<CascadePlanIn> plan(nlaunches);
+  for (int q = 0; q < nlaunches; q++) plan[q] = {group[q], work[q]};
+  std::vector<std::vector<int>> pl(ngroups);
+  for (int g = 0; g < ngroups; g++) {
+    if (pool_begin[g + 1] < pool_begin[g]) return SACAMD_ERR_ARG;
+    for (int i = pool_begin[g]; i < pool_begin[g + 1]; i++) { if (pool[i] < 0 || pool[i] >= 4096) return SACAMD_ERR_ARG; pl[g].push_back(pool[i]); }
+  }
+  std::vector<size_t> ord; std::vector<int> st;
+  if (!plan_cascade_streams(plan, pl, small_work, ord, st)) return SACAMD_ERR_ARG;
+  for (int q = 0; q < nlaunches; q++) { order[q] = (int)ord[q]; stream[q] = st[q]; }
   return 0;
 }
 

@@ -39,7 +39,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     import sac_amd.api as api
     assert sorted(api.ABI_SYMBOLS) == declared
-    assert lib.sacamd_abi_version() == api.ABI_VERSION == 6
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 7
     # without a GPU the context constructor must fail loudly (no CPU fallback)
     import torch
     if not torch.cuda.is_available():
@@ -59,6 +59,37 @@ def test_inline_asm_dpp_instructions_have_no_hazard_producers():
     n, bad = mod.check(os.path.join(ROOT, "sac_amd", "libsac_amd.so"))
     assert n > 1000, n                       # the grid kernels' backward solves are there
     assert not bad, bad[:5]
+
+
+def test_cascade_launch_plan_keeps_small_launches_off_the_busy_streams():
+    """sacamd_plan_cascade_streams (launch_plan.h), the planner run_predict uses.  The case is the late cascade group of the
+    final pass of the 1536-frame step (profiles/r06/launch_trace_1536_before_streams.txt): two throughput-bound launches and
+    seven launches of 1-39 items on five streams.  Balanced by taps, four of the small ones had queued behind one another."""
+    import sac_amd.api as api
+    n = 882000.0
+    items = [879, 590, 12, 39, 5, 4, 1, 1, 1]
+    taps = [7000, 4000, 7500, 1500, 7500, 7500, 7600, 7400, 7300]
+    work = [i * t * n for i, t in zip(items, taps)]
+    order, stream = api.plan_cascade_streams([1] * 9, work, [[8, 9, 10, 11, 0, 1, 2], [3, 4, 5, 6, 7]], 1.5e6 * n)
+    assert sorted(order.tolist()) == list(range(9)) and order[0] == 0 and order[1] == 1            # longest first
+    assert set(stream.tolist()) <= {3, 4, 5, 6, 7}                                                 # the group's own pool
+    big = {int(stream[0]), int(stream[1])}
+    assert len(big) == 2
+    small = [int(stream[q]) for q in range(2, 9)]
+    assert not (set(small) & big)                                                                  # never behind a launch that ends with the chip's drain
+    assert max(small.count(s) for s in set(small)) == 3 and len(set(small)) == 3                   # 7 over 3 streams: 3 + 2 + 2
+    # every stream of the pool busy (a search generation): small launches queue behind the SMALLEST throughput-bound launch
+    work2 = [1e300, 9e6 * n, 8e6 * n, 7e6 * n, 2e6 * n, 1e5 * n, 2e5 * n]
+    order2, stream2 = api.plan_cascade_streams([0] * 7, work2, [[3, 4, 5, 6, 7]], 5e5 * n)
+    assert order2[0] == 0                                                                          # the whole-CU layout is issued first
+    assert stream2[5] == stream2[6] == stream2[4] and len(set(stream2[:5].tolist())) == 5
+    # groups are planned independently and in group order; a group without streams is an argument error
+    order3, stream3 = api.plan_cascade_streams([1, 0, 1, 0], [5e6, 1e6, 9e6, 3e6], [[0, 1], [2, 3]], 1.0)
+    assert order3.tolist() == [3, 1, 2, 0] and stream3.tolist() == [3, 1, 2, 0]
+    with pytest.raises(api.SacAmdError):
+        api.plan_cascade_streams([1], [1.0], [[0], []], 1.0)
+    o0, s0 = api.plan_cascade_streams([], [], [[0]], 1.0)
+    assert len(o0) == 0 and len(s0) == 0
 
 
 def test_default_profile_matches_reference(golden):

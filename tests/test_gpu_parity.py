@@ -28,7 +28,7 @@ def gpu_cfg(api, cfg):
 
 def test_library_is_the_hip_one(api):
     lib = api.load_library()
-    assert lib.sacamd_abi_version() == api.ABI_VERSION == 6
+    assert lib.sacamd_abi_version() == api.ABI_VERSION == 7
     ctx = api.Context(2, 1000, 1)   # fails loudly without a gfx950 device
     ctx.close()
     assert np.array_equal(api.default_profile(), np.load(__import__("os").path.join(
